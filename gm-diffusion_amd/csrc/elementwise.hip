@@ -1,0 +1,150 @@
+// Small HBM-bound elementwise kernels of the UNet: GEGLU gate, sinusoidal timestep embedding,
+// channel concat (skip connections) and dtype cast.  16-byte accesses throughout.
+#include "gmd_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void geglu_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int F) {
+    constexpr int V = Elem<T>::kVec;
+    const int FV = F / V;
+    const int64_t total = rows * FV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / FV;
+        const int f = (int)(i - r * FV) * V;
+        float h[V], g[V];
+        load_vec(X + r * 2 * F + f, h);
+        load_vec(X + r * 2 * F + F + f, g);
+#pragma unroll
+        for (int j = 0; j < V; ++j) h[j] = h[j] * gelu_erf(g[j]);
+        store_vec(Y + r * F + f, h);
+    }
+}
+
+// diffusers get_timestep_embedding: emb_i = t * exp(-ln(10000) * i / (half - shift)); [sin | cos], flipped to [cos | sin]
+template <typename T>
+__global__ void temb_kernel(const float* __restrict__ t_dev, T* __restrict__ out, int B, int dim, int flip, float shift) {
+    const int half = dim / 2;
+    const float t = *t_dev;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * half; i += gridDim.x * blockDim.x) {
+        const int b = i / half, k = i - b * half;
+        const float e = expf(-9.210340371976184f * (float)k / ((float)half - shift));
+        const float a = t * e;
+        const float sn = sinf(a), cs = cosf(a);
+        T* o = out + (int64_t)b * dim;
+        Elem<T>::st(o + (flip ? half + k : k), sn);
+        Elem<T>::st(o + (flip ? k : half + k), cs);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void concat_kernel(const T* __restrict__ A, int Ca, const T* __restrict__ Bm, int Cb,
+                                                          T* __restrict__ out, int64_t rows) {
+    constexpr int V = Elem<T>::kVec;
+    const int CV = (Ca + Cb) / V, CaV = Ca / V;
+    const int64_t total = rows * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / CV;
+        const int c = (int)(i - r * CV);
+        const uint4 v = c < CaV ? *reinterpret_cast<const uint4*>(A + r * Ca + (int64_t)c * V)
+                                : *reinterpret_cast<const uint4*>(Bm + r * Cb + (int64_t)(c - CaV) * V);
+        *reinterpret_cast<uint4*>(out + i * V) = v;
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kThreads) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<TO>::st(out + i, Elem<TI>::ld(in + i));
+}
+
+inline int grid_for(int64_t n) {
+    int64_t g = (n + kThreads - 1) / kThreads;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmd_geglu(const void* X, void* Y, int dtype, int64_t rows, int F, gmd_stream_t stream) {
+    GMD_REQUIRE(rows >= 0 && F > 0, "gmd_geglu: bad shape");
+    if (rows == 0) return GMD_OK;
+    GMD_REQUIRE(X && Y && gmd_aligned16(X) && gmd_aligned16(Y), "gmd_geglu: null or unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GMD_BF16) {
+        GMD_REQUIRE(F % 8 == 0, "gmd_geglu: F=%d must be a multiple of 8", F);
+        geglu_kernel<bf16_t><<<grid_for(rows * (F / 8)), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, F);
+    } else if (dtype == GMD_F32) {
+        GMD_REQUIRE(F % 4 == 0, "gmd_geglu: F=%d must be a multiple of 4", F);
+        geglu_kernel<float><<<grid_for(rows * (F / 4)), kThreads, 0, s>>>((const float*)X, (float*)Y, rows, F);
+    } else {
+        GMD_REQUIRE(false, "gmd_geglu: bad dtype %d", dtype);
+    }
+    GMD_CHECK_LAUNCH("gmd_geglu");
+    return GMD_OK;
+}
+
+int gmd_timestep_embedding(const float* t_dev, void* out, int dtype, int B, int dim, int flip_sin_to_cos, float freq_shift,
+                           gmd_stream_t stream) {
+    GMD_REQUIRE(B > 0 && dim > 0 && dim % 2 == 0, "gmd_timestep_embedding: bad shape B=%d dim=%d", B, dim);
+    GMD_REQUIRE(t_dev && out, "gmd_timestep_embedding: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (B * dim / 2 + 255) / 256;
+    if (dtype == GMD_BF16)
+        temb_kernel<bf16_t><<<grid, 256, 0, s>>>(t_dev, (bf16_t*)out, B, dim, flip_sin_to_cos, freq_shift);
+    else if (dtype == GMD_F32)
+        temb_kernel<float><<<grid, 256, 0, s>>>(t_dev, (float*)out, B, dim, flip_sin_to_cos, freq_shift);
+    else
+        GMD_REQUIRE(false, "gmd_timestep_embedding: bad dtype %d", dtype);
+    GMD_CHECK_LAUNCH("gmd_timestep_embedding");
+    return GMD_OK;
+}
+
+int gmd_concat_channels(const void* A, int Ca, const void* Bm, int Cb, void* out, int dtype, int64_t rows, gmd_stream_t stream) {
+    GMD_REQUIRE(rows >= 0 && Ca > 0 && Cb > 0, "gmd_concat_channels: bad shape");
+    if (rows == 0) return GMD_OK;
+    GMD_REQUIRE(A && Bm && out, "gmd_concat_channels: null pointer");
+    GMD_REQUIRE(gmd_aligned16(A) && gmd_aligned16(Bm) && gmd_aligned16(out), "gmd_concat_channels: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GMD_BF16) {
+        GMD_REQUIRE(Ca % 8 == 0 && Cb % 8 == 0, "gmd_concat_channels: channel counts must be multiples of 8");
+        concat_kernel<bf16_t><<<grid_for(rows * ((Ca + Cb) / 8)), kThreads, 0, s>>>((const bf16_t*)A, Ca, (const bf16_t*)Bm, Cb, (bf16_t*)out, rows);
+    } else if (dtype == GMD_F32) {
+        GMD_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, "gmd_concat_channels: channel counts must be multiples of 4");
+        concat_kernel<float><<<grid_for(rows * ((Ca + Cb) / 4)), kThreads, 0, s>>>((const float*)A, Ca, (const float*)Bm, Cb, (float*)out, rows);
+    } else {
+        GMD_REQUIRE(false, "gmd_concat_channels: bad dtype %d", dtype);
+    }
+    GMD_CHECK_LAUNCH("gmd_concat_channels");
+    return GMD_OK;
+}
+
+int gmd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, gmd_stream_t stream) {
+    GMD_REQUIRE(n >= 0, "gmd_cast: negative n");
+    if (n == 0) return GMD_OK;
+    GMD_REQUIRE(in && out, "gmd_cast: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n);
+    if (in_dtype == GMD_F32 && out_dtype == GMD_BF16)
+        cast_kernel<float, bf16_t><<<grid, kThreads, 0, s>>>((const float*)in, (bf16_t*)out, n);
+    else if (in_dtype == GMD_BF16 && out_dtype == GMD_F32)
+        cast_kernel<bf16_t, float><<<grid, kThreads, 0, s>>>((const bf16_t*)in, (float*)out, n);
+    else if (in_dtype == GMD_F32 && out_dtype == GMD_F32)
+        cast_kernel<float, float><<<grid, kThreads, 0, s>>>((const float*)in, (float*)out, n);
+    else if (in_dtype == GMD_BF16 && out_dtype == GMD_BF16)
+        cast_kernel<bf16_t, bf16_t><<<grid, kThreads, 0, s>>>((const bf16_t*)in, (bf16_t*)out, n);
+    else
+        GMD_REQUIRE(false, "gmd_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+    GMD_CHECK_LAUNCH("gmd_cast");
+    return GMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,298 @@
+// GroupNorm (statistics + fused affine/SiLU apply), LayerNorm and row softmax over
+// channels-last activations.  HBM-bound: 16-byte accesses, wave-shuffle reductions, and a
+// fixed (deterministic) reduction order everywhere -- no float atomics.
+#include "gmd_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics.  grid (nsplit, B); each block reduces a contiguous pixel range.
+// Thread t owns channel chunk (t % CVB) (+ column-block offset) of pixel row (t / CVB):
+// per-channel partials go to LDS [PY][C], then thread g < G folds its group's channels in a
+// fixed order and writes {sum, sumsq} to workspace[b][split][g].
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_partial_kernel(const T* __restrict__ X, int64_t HW, int C, int G,
+                                                              int nsplit, float* __restrict__ ws) {
+    constexpr int V = Elem<T>::kVec;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [PY][C] sums, [PY][C] sumsq
+    const int b = blockIdx.y, split = blockIdx.x;
+    const int CV = C / V;
+    const int CVB = CV < kThreads ? CV : kThreads;
+    const int PY = kThreads / CVB;
+    const int py = threadIdx.x / CVB, cx = threadIdx.x % CVB;
+    const int64_t per = (HW + nsplit - 1) / nsplit;
+    const int64_t p0 = (int64_t)split * per;
+    const int64_t p1 = (p0 + per < HW) ? p0 + per : HW;
+    float* s_sum = smem;
+    float* s_sq = smem + (size_t)PY * C;
+    const T* Xb = X + (int64_t)b * HW * C;
+    for (int cb = 0; cb < CV; cb += CVB) {
+        const int chunk = cb + cx;
+        float a[V], q[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) a[j] = q[j] = 0.0f;
+        if (py < PY && chunk < CV) {
+            for (int64_t p = p0 + py; p < p1; p += PY) {
+                float v[V];
+                load_vec(Xb + p * C + (int64_t)chunk * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { a[j] += v[j]; q[j] += v[j] * v[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s_sum[(size_t)py * C + chunk * V + j] = a[j];
+                s_sq[(size_t)py * C + chunk * V + j] = q[j];
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+        const int g = threadIdx.x, cpg = C / G;
+        double s = 0.0, s2 = 0.0;
+        for (int r = 0; r < PY; ++r)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += s_sum[(size_t)r * C + c]; s2 += s_sq[(size_t)r * C + c]; }
+        float* o = ws + (((int64_t)b * nsplit + split) * G + g) * 2;
+        o[0] = (float)s;
+        o[1] = (float)s2;
+    }
+}
+
+// grid B: fold the splits (fixed order, double), then per-channel affine
+__global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __restrict__ ws, int nsplit, int64_t HW, int C,
+                                                               int G, float eps, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ ss) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int b = blockIdx.x, cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double s = 0.0, s2 = 0.0;
+        for (int k = 0; k < nsplit; ++k) {
+            const float* o = ws + (((int64_t)b * nsplit + k) * G + g) * 2;
+            s += o[0]; s2 += o[1];
+        }
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * gamma[c];
+        ss[((int64_t)b * C + c) * 2] = sc;
+        ss[((int64_t)b * C + c) * 2 + 1] = beta[c] - s_mean[g] * sc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ X, T* __restrict__ Y, int B, int64_t HW, int C,
+                                                            const float* __restrict__ ss, int silu) {
+    constexpr int V = Elem<T>::kVec;
+    const int CV = C / V;
+    const int64_t total = (int64_t)B * HW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int chunk = (int)(i % CV);
+        const int64_t b = i / ((int64_t)HW * CV);
+        float v[V];
+        load_vec(X + i * V, v);
+        const float* p = ss + ((int64_t)b * C + (int64_t)chunk * V) * 2;
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {
+            const float4 q = *reinterpret_cast<const float4*>(p + 2 * j);
+            v[j] = v[j] * q.x + q.y;
+            v[j + 1] = v[j + 1] * q.z + q.w;
+        }
+        if (silu) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = silu_f(v[j]);
+        }
+        store_vec(Y + i * V, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers, exact two-pass variance.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(kThreads) void layernorm_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int C,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps) {
+    constexpr int V = Elem<T>::kVec;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int CV = C / V;
+    float v[MAXCH][V];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int chunk = lane + 64 * k;
+        if (chunk < CV) {
+            load_vec(X + row * C + (int64_t)chunk * V, v[k]);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s += v[k][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[k][j] = 0.0f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        if (lane + 64 * k < CV) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = v[k][j] - mean; s2 += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int chunk = lane + 64 * k;
+        if (chunk < CV) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int c = chunk * V + j;
+                o[j] = (v[k][j] - mean) * rstd * gamma[c] + beta[c];
+            }
+            store_vec(Y + row * C + (int64_t)chunk * V, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax (float32 logits -> T probabilities), one block per row, three passes.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, T* __restrict__ P,
+                                                                int64_t ldp, int cols, float scale) {
+    __shared__ float red[kThreads / 64];
+    const int64_t row = blockIdx.x;
+    const float* s = S + row * lds_;
+    T* p = P + row * ldp;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += kThreads) m = fmaxf(m, s[c] * scale);
+    m = wave_max(m);
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.0f;
+    for (int c = threadIdx.x; c < cols; c += kThreads) sum += expf(s[c] * scale - m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / sum;
+    for (int c = threadIdx.x; c < (int)ldp; c += kThreads)
+        Elem<T>::st(p + c, c < cols ? expf(s[c] * scale - m) * inv : 0.0f);
+}
+
+inline int grid_for(int64_t n) {
+    int64_t g = (n + kThreads - 1) / kThreads;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmd_groupnorm_nsplit(int64_t HW) {
+    int64_t n = HW / 128;
+    if (n < 1) n = 1;
+    if (n > 256) n = 256;
+    return (int)n;
+}
+
+int gmd_groupnorm_stats(const void* X, int dtype, int B, int64_t HW, int C, int G, float eps, const float* gamma,
+                        const float* beta, float* workspace, float* scale_shift, gmd_stream_t stream) {
+    GMD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64, "gmd_groupnorm_stats: bad shape B=%d HW=%lld C=%d G=%d", B, (long long)HW, C, G);
+    GMD_REQUIRE(C % G == 0, "gmd_groupnorm_stats: C=%d not divisible by G=%d", C, G);
+    GMD_REQUIRE(X && gamma && beta && workspace && scale_shift, "gmd_groupnorm_stats: null pointer");
+    GMD_REQUIRE(gmd_aligned16(X), "gmd_groupnorm_stats: X not 16-byte aligned");
+    const int V = dtype == GMD_BF16 ? 8 : 4;
+    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_groupnorm_stats: bad dtype %d", dtype);
+    GMD_REQUIRE(C % V == 0, "gmd_groupnorm_stats: C=%d must be a multiple of %d", C, V);
+    const int nsplit = gmd_groupnorm_nsplit(HW);
+    const int CV = C / V, CVB = CV < kThreads ? CV : kThreads, PY = kThreads / CVB;
+    const size_t smem = (size_t)PY * C * 2 * sizeof(float);
+    GMD_REQUIRE(smem <= 64 * 1024, "gmd_groupnorm_stats: C=%d too large", C);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nsplit, B);
+    if (dtype == GMD_BF16)
+        gn_partial_kernel<bf16_t><<<grid, kThreads, smem, s>>>((const bf16_t*)X, HW, C, G, nsplit, workspace);
+    else
+        gn_partial_kernel<float><<<grid, kThreads, smem, s>>>((const float*)X, HW, C, G, nsplit, workspace);
+    GMD_CHECK_LAUNCH("gmd_groupnorm_stats(partial)");
+    gn_finalize_kernel<<<B, kThreads, 0, s>>>(workspace, nsplit, HW, C, G, eps, gamma, beta, scale_shift);
+    GMD_CHECK_LAUNCH("gmd_groupnorm_stats(finalize)");
+    return GMD_OK;
+}
+
+int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, int C, const float* scale_shift, int silu,
+                        gmd_stream_t stream) {
+    GMD_REQUIRE(B > 0 && HW > 0 && C > 0, "gmd_groupnorm_apply: bad shape");
+    GMD_REQUIRE(X && Y && scale_shift, "gmd_groupnorm_apply: null pointer");
+    GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y) && gmd_aligned16(scale_shift), "gmd_groupnorm_apply: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GMD_BF16) {
+        GMD_REQUIRE(C % 8 == 0, "gmd_groupnorm_apply: C=%d must be a multiple of 8", C);
+        gn_apply_kernel<bf16_t><<<grid_for((int64_t)B * HW * (C / 8)), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, B, HW, C, scale_shift, silu);
+    } else if (dtype == GMD_F32) {
+        GMD_REQUIRE(C % 4 == 0, "gmd_groupnorm_apply: C=%d must be a multiple of 4", C);
+        gn_apply_kernel<float><<<grid_for((int64_t)B * HW * (C / 4)), kThreads, 0, s>>>((const float*)X, (float*)Y, B, HW, C, scale_shift, silu);
+    } else {
+        GMD_REQUIRE(false, "gmd_groupnorm_apply: bad dtype %d", dtype);
+    }
+    GMD_CHECK_LAUNCH("gmd_groupnorm_apply");
+    return GMD_OK;
+}
+
+int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                  gmd_stream_t stream) {
+    GMD_REQUIRE(rows >= 0 && C > 0 && C <= 2048, "gmd_layernorm: bad shape rows=%lld C=%d", (long long)rows, C);
+    if (rows == 0) return GMD_OK;
+    GMD_REQUIRE(X && Y && gamma && beta, "gmd_layernorm: null pointer");
+    GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y), "gmd_layernorm: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)((rows + 3) / 4);
+    if (dtype == GMD_BF16) {
+        GMD_REQUIRE(C % 8 == 0, "gmd_layernorm: C=%d must be a multiple of 8", C);
+        layernorm_kernel<bf16_t, 4><<<grid, kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
+    } else if (dtype == GMD_F32) {
+        GMD_REQUIRE(C % 4 == 0, "gmd_layernorm: C=%d must be a multiple of 4", C);
+        layernorm_kernel<float, 8><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, rows, C, gamma, beta, eps);
+    } else {
+        GMD_REQUIRE(false, "gmd_layernorm: bad dtype %d", dtype);
+    }
+    GMD_CHECK_LAUNCH("gmd_layernorm");
+    return GMD_OK;
+}
+
+int gmd_softmax_rows(const float* S, int64_t lds_, void* P, int out_dtype, int64_t ldp, int64_t rows, int cols, float scale,
+                     gmd_stream_t stream) {
+    GMD_REQUIRE(rows >= 0 && cols > 0 && lds_ >= cols && ldp >= cols, "gmd_softmax_rows: bad shape");
+    if (rows == 0) return GMD_OK;
+    GMD_REQUIRE(S && P, "gmd_softmax_rows: null pointer");
+    GMD_REQUIRE(rows < (1LL << 31), "gmd_softmax_rows: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == GMD_BF16)
+        softmax_rows_kernel<bf16_t><<<(int)rows, kThreads, 0, s>>>(S, lds_, (bf16_t*)P, ldp, cols, scale);
+    else if (out_dtype == GMD_F32)
+        softmax_rows_kernel<float><<<(int)rows, kThreads, 0, s>>>(S, lds_, (float*)P, ldp, cols, scale);
+    else
+        GMD_REQUIRE(false, "gmd_softmax_rows: bad dtype %d", out_dtype);
+    GMD_CHECK_LAUNCH("gmd_softmax_rows");
+    return GMD_OK;
+}
+
+}  // extern "C"

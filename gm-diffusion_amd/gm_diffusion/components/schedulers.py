@@ -1,0 +1,291 @@
+"""
+Schedulers for the MI355X build: ``PNDMScheduler`` (PLMS, the "50 PNDM steps" configuration of
+scripts/stage2/train_gm_unet.py:171-176) and ``DDPMScheduler``
+(scripts/inference/generate_hdr.py:162).  In the reference both come from ``diffusers``; these
+classes keep the protocol the pipelines rely on (stable_diffusion_gm.py:216-241, 610-625, 715,
+1037, 1048, 1071; stable_diffusion_dual_unet.py:1037, 1072): ``config`` (dict-like, attribute
+access), ``set_timesteps``, ``timesteps``, ``order``, ``init_noise_sigma``,
+``scale_model_input``, ``step(...)``, ``alphas_cumprod``, ``from_config`` and survival under
+``copy.deepcopy``.
+
+The schedulers are host-side state machines; the per-element update runs in the
+``gmd_latent_step`` HIP kernel for device tensors (same float32 operation order as the torch
+expressions, so the two agree bit for bit) and in plain torch for host tensors, which is what the
+reference itself executes on CPU tensors.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .. import hip_ops as ops
+from .configuration import ConfigMixin
+from .image_processor import _Output, randn_tensor
+
+
+@dataclass
+class SchedulerOutput(_Output):
+    prev_sample: torch.Tensor
+
+
+def _betas(beta_schedule, beta_start, beta_end, n, trained_betas=None):
+    if trained_betas is not None:
+        return torch.tensor(trained_betas, dtype=torch.float32)
+    if beta_schedule == "linear":
+        return torch.linspace(beta_start, beta_end, n, dtype=torch.float32)
+    if beta_schedule == "scaled_linear":
+        return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    raise NotImplementedError(f"{beta_schedule} is not implemented")
+
+
+class _SchedulerBase(ConfigMixin):
+    config_name = "scheduler_config.json"
+    order = 1
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **overrides):
+        d = os.path.join(path, subfolder) if subfolder else path
+        return cls.from_config(cls.load_config(d), **overrides)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+class PNDMScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, skip_prk_steps=False, set_alpha_to_one=False, prediction_type="epsilon",
+                     timestep_spacing="leading", steps_offset=0, clip_sample=False)
+
+    def __init__(self, **kwargs):
+        cfg = dict(self._defaults)
+        bad = [k for k in kwargs if k not in cfg]
+        if bad:
+            raise TypeError(f"PNDMScheduler: unexpected arguments {bad}")
+        cfg.update(kwargs)
+        self.register_to_config(**cfg)
+        if cfg["prediction_type"] != "epsilon":
+            raise NotImplementedError("only epsilon prediction is implemented")
+        self.betas = _betas(cfg["beta_schedule"], cfg["beta_start"], cfg["beta_end"], cfg["num_train_timesteps"], cfg["trained_betas"])
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if cfg["set_alpha_to_one"] else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.pndm_order = 4
+        self.cur_model_output = 0
+        self.counter = 0
+        self.cur_sample = None
+        self.ets = []
+        self.num_inference_steps = None
+        self._timesteps = np.arange(0, cfg["num_train_timesteps"])[::-1].copy()
+        self.prk_timesteps = None
+        self.plms_timesteps = None
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        c = self.config
+        self.num_inference_steps = num_inference_steps
+        if c.timestep_spacing == "linspace":
+            self._timesteps = np.linspace(0, c.num_train_timesteps - 1, num_inference_steps).round().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ratio = c.num_train_timesteps // num_inference_steps
+            self._timesteps = (np.arange(0, num_inference_steps) * ratio).round()
+            self._timesteps += c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ratio = c.num_train_timesteps / num_inference_steps
+            self._timesteps = np.round(np.arange(c.num_train_timesteps, 0, -ratio))[::-1].astype(np.int64)
+            self._timesteps -= 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported")
+        if c.skip_prk_steps:
+            self.prk_timesteps = np.array([])
+            self.plms_timesteps = np.concatenate([self._timesteps[:-1], self._timesteps[-2:-1], self._timesteps[-1:]])[::-1].copy()
+        else:
+            raise NotImplementedError("Runge-Kutta warm-up (skip_prk_steps=False) is not implemented; SD-1.5 uses skip_prk_steps=True")
+        timesteps = np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64)
+        self.timesteps = torch.from_numpy(timesteps).to(device)
+        self.ets = []
+        self.counter = 0
+        self.cur_model_output = 0
+        self.cur_sample = None
+
+    # ---- PLMS planning (host) ------------------------------------------------------------------
+    def _plan(self, timestep):
+        """Which PLMS branch the next step takes: (mode, effective timestep, previous timestep)."""
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        timestep = int(timestep)
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        prev = timestep - ratio
+        n_after = len(self.ets[-3:]) + 1 if self.counter != 1 else len(self.ets)
+        if self.counter == 1:
+            prev, timestep = timestep, timestep + ratio
+        if n_after == 1 and self.counter == 0:
+            mode = 0
+        elif n_after == 1 and self.counter == 1:
+            mode = 1
+        else:
+            mode = min(n_after, 4)
+        return mode, timestep, prev
+
+    def _coefs(self, timestep, prev_timestep):
+        """diffusers ``_get_prev_sample`` coefficients, evaluated on float32 0-d tensors exactly as there."""
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        sample_coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        return sample_coeff, a_prev - a_t, denom
+
+    def _commit(self, mode, eps, sample):
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(eps)
+        if mode == 0:
+            self.cur_sample = sample
+        elif mode == 1:
+            self.cur_sample = None
+        self.counter += 1
+
+    def step(self, model_output, timestep, sample, return_dict=True):
+        mode, t_eff, prev = self._plan(timestep)
+        sc, ad, dn = self._coefs(t_eff, prev)
+        if model_output.is_cuda:
+            hist = [e for e in reversed(self.ets[-3:])] if self.counter != 1 else [self.ets[-1]]
+            x = sample.contiguous()
+            nh = {0: 0, 1: 1, 2: 1, 3: 2, 4: 3}[mode]
+            _, prev_sample, _ = ops.latent_step(model_output.contiguous(), x, mode, (sc.item(), ad.item(), dn.item(), 1.0, 0.0),
+                                                False, 1.0, cur_sample=self.cur_sample, hist=hist[:nh])
+            self._commit(mode, model_output, sample)
+        else:
+            e = (self.ets[-3:] + [model_output]) if self.counter != 1 else self.ets
+            smp = sample
+            if mode == 0:
+                m = model_output
+            elif mode == 1:
+                m = (model_output + e[-1]) / 2
+                smp = self.cur_sample
+            elif mode == 2:
+                m = (3 * e[-1] - e[-2]) / 2
+            elif mode == 3:
+                m = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12
+            else:
+                m = (1 / 24) * (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4])
+            prev_sample = sc * smp - ad * m / dn
+            self._commit(mode, model_output, sample)
+        return (prev_sample,) if not return_dict else SchedulerOutput(prev_sample=prev_sample)
+
+    def fused_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale=0.0, want_x0=False):
+        """CFG combine (+rescale) + x0 + PLMS update in ONE HIP kernel pass (device tensors only).
+        eps_in: raw UNet output ([2B,...] when do_cfg).  Returns (prev_sample, x0 | None)."""
+        mode, t_eff, prev = self._plan(timestep)
+        sc, ad, dn = self._coefs(t_eff, prev)
+        a = self.alphas_cumprod[int(timestep)]  # dual_unet.py:1072 uses the loop timestep
+        ratio = None
+        if do_cfg and guidance_rescale > 0.0:
+            ratio = ops.cfg_std_ratio(eps_in, guidance_scale)
+        hist = [e for e in reversed(self.ets[-3:])] if self.counter != 1 else [self.ets[-1]]
+        nh = {0: 0, 1: 1, 2: 1, 3: 2, 4: 3}[mode]
+        eps, prev_sample, x0 = ops.latent_step(eps_in, sample.contiguous(), mode,
+                                               (sc.item(), ad.item(), dn.item(), a.sqrt().item(), (1 - a).sqrt().item()),
+                                               do_cfg, guidance_scale, cur_sample=self.cur_sample, hist=hist[:nh], ratio=ratio,
+                                               guidance_rescale=guidance_rescale, want_x0=want_x0)
+        self._commit(mode, eps, sample)
+        return prev_sample, x0
+
+
+class DDPMScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                     variance_type="fixed_small", clip_sample=True, prediction_type="epsilon", thresholding=False,
+                     dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
+                     timestep_spacing="leading", steps_offset=0, rescale_betas_zero_snr=False)
+
+    def __init__(self, **kwargs):
+        cfg = dict(self._defaults)
+        bad = [k for k in kwargs if k not in cfg]
+        if bad:
+            raise TypeError(f"DDPMScheduler: unexpected arguments {bad}")
+        cfg.update(kwargs)
+        self.register_to_config(**cfg)
+        if cfg["prediction_type"] != "epsilon" or cfg["thresholding"] or cfg["rescale_betas_zero_snr"]:
+            raise NotImplementedError("only epsilon prediction without thresholding / zero-SNR rescale is implemented")
+        if cfg["variance_type"] not in ("fixed_small", "fixed_small_log", "fixed_large"):
+            raise NotImplementedError(cfg["variance_type"])
+        self.betas = _betas(cfg["beta_schedule"], cfg["beta_start"], cfg["beta_end"], cfg["num_train_timesteps"], cfg["trained_betas"])
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.init_noise_sigma = 1.0
+        self.custom_timesteps = False
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, cfg["num_train_timesteps"])[::-1].copy())
+
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None):
+        c = self.config
+        if timesteps is not None:
+            timesteps = np.array(timesteps, dtype=np.int64)
+            self.custom_timesteps = True
+            self.num_inference_steps = len(timesteps)
+        else:
+            if num_inference_steps > c.num_train_timesteps:
+                raise ValueError("num_inference_steps cannot exceed num_train_timesteps")
+            self.num_inference_steps = num_inference_steps
+            self.custom_timesteps = False
+            if c.timestep_spacing == "linspace":
+                timesteps = np.linspace(0, c.num_train_timesteps - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+            elif c.timestep_spacing == "leading":
+                ratio = c.num_train_timesteps // num_inference_steps
+                timesteps = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+                timesteps += c.steps_offset
+            elif c.timestep_spacing == "trailing":
+                ratio = c.num_train_timesteps / num_inference_steps
+                timesteps = np.round(np.arange(c.num_train_timesteps, 0, -ratio)).astype(np.int64) - 1
+            else:
+                raise ValueError(f"{c.timestep_spacing} is not supported")
+        self.timesteps = torch.from_numpy(timesteps).to(device)
+
+    def previous_timestep(self, timestep):
+        if self.custom_timesteps:
+            idx = (self.timesteps == timestep).nonzero(as_tuple=True)[0][0]
+            return torch.tensor(-1) if idx == self.timesteps.shape[0] - 1 else self.timesteps[idx + 1]
+        n = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
+        return timestep - self.config.num_train_timesteps // n
+
+    def _get_variance(self, t):
+        prev_t = self.previous_timestep(t)
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        cur_b = 1 - a_t / a_p
+        variance = torch.clamp((1 - a_p) / (1 - a_t) * cur_b, min=1e-20)
+        vt = self.config.variance_type
+        if vt == "fixed_small_log":
+            variance = torch.exp(0.5 * torch.log(variance))
+        elif vt == "fixed_large":
+            variance = cur_b
+        return variance
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        t = int(timestep)
+        prev_t = int(self.previous_timestep(t))
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        b_t, b_p = 1 - a_t, 1 - a_p
+        cur_a = a_t / a_p
+        cur_b = 1 - cur_a
+        dev = model_output.device
+        x0 = (sample - (b_t ** 0.5).to(dev) * model_output) / (a_t ** 0.5).to(dev)
+        if self.config.clip_sample:
+            x0 = x0.clamp(-self.config.clip_sample_range, self.config.clip_sample_range)
+        x0_coeff = ((a_p ** 0.5 * cur_b) / b_t).to(dev)
+        xt_coeff = (cur_a ** 0.5 * b_p / b_t).to(dev)
+        prev = x0_coeff * x0 + xt_coeff * sample
+        if t > 0:
+            noise = randn_tensor(model_output.shape, generator=generator, device=dev, dtype=model_output.dtype)
+            v = self._get_variance(t).to(dev)
+            prev = prev + (v * noise if self.config.variance_type == "fixed_small_log" else (v ** 0.5) * noise)
+        return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)

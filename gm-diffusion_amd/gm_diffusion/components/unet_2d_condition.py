@@ -1,0 +1,541 @@
+"""
+``UNet2DConditionModel`` for the MI355X build -- the denoiser the reference pipelines call at
+gm_diffusion/pipelines/stable_diffusion_gm.py:1051-1059 and
+stable_diffusion_dual_unet.py:1052-1060, 1083-1092:
+
+    unet(sample, t, encoder_hidden_states=..., return_dict=False)[0]
+
+In the reference this is ``diffusers.UNet2DConditionModel`` (un-vendored dependency) with the
+SD-1.5 hyper-parameters hard-coded at scripts/inference/generate_hdr.py:116-135 and
+``in_channels`` 4 (SDR UNet) or 8 (GM UNet).  Here the same network runs entirely on the
+hand-written HIP kernels of libgmd_hip.so over channels-last activations:
+
+  * conv3x3 (+bias +time-embedding +residual)      -> gmd_conv3x3 (implicit GEMM, MFMA)
+  * Linear / conv1x1 (+bias +residual +SiLU)       -> gmd_gemm_nt
+  * GroupNorm(+SiLU), LayerNorm, GEGLU              -> gmd_groupnorm_*, gmd_layernorm, gmd_geglu
+  * self / cross attention                          -> gmd_attention (bf16) or GEMM+softmax+GEMM (f32)
+  * 8-channel concat / CFG duplicate / layout+cast  -> gmd_pack_unet_input, gmd_unpack_nchw
+
+State-dict keys follow diffusers so a real SD-1.5 checkpoint loads.
+There is no CPU path: ``forward`` raises ``HipExtensionError`` off-device.
+
+dtype policy: weights/activations are ``self.dtype`` (bfloat16 = MFMA path, float32 = parity
+path); the input latents are float32 NCHW and are cast while being packed; the output eps is
+float32 NCHW taken from the fp32 accumulators of ``conv_out`` (never rounded to bf16).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import hip_ops as ops
+from .._native import HipExtensionError
+from .configuration import ConfigMixin, read_state_dict
+
+SD15_UNET_DEFAULTS = dict(
+    sample_size=64, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1, mid_block_scale_factor=1,
+    act_fn="silu", norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=768, attention_head_dim=8,
+    time_cond_proj_dim=None,
+)
+
+
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class _HipModule(ConfigMixin):
+    """Shared weight handling: raw CPU float32 state-dict -> device tensors in kernel layouts."""
+
+    def _init_module(self):
+        self._raw = None       # diffusers-keyed CPU float32 tensors
+        self._w = None         # prepared device tensors
+        self._dtype = torch.float32
+        self._device = torch.device("cpu")
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def state_dict(self):
+        return dict(self._raw or {})
+
+    def load_state_dict(self, sd, strict=True):
+        want = self.expected_keys()
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in want]
+        if strict and (missing or unexpected):
+            raise KeyError(f"{type(self).__name__}.load_state_dict: missing={missing[:5]} (+{max(len(missing) - 5, 0)}) "
+                           f"unexpected={unexpected[:5]} (+{max(len(unexpected) - 5, 0)})")
+        bad = [k for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k])]
+        if bad:
+            raise ValueError(f"shape mismatch for {bad[:5]}: e.g. {tuple(sd[bad[0]].shape)} vs {tuple(want[bad[0]])}")
+        self._raw = {k: sd[k].detach().to("cpu", torch.float32) for k in want if k in sd}
+        self._w = None
+        return self
+
+    def to(self, *args, **kwargs):
+        device, dtype = kwargs.get("device"), kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif a is not None:
+                device = a
+        if dtype is not None:
+            if dtype == torch.float16:
+                raise HipExtensionError("float16 is not implemented in the MI355X build; use bfloat16 or float32")
+            self._dtype = dtype
+        if device is not None:
+            self._device = torch.device(device)
+        self._w = None
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def _ensure(self):
+        if self._w is not None:
+            return
+        if self._raw is None:
+            raise RuntimeError(f"{type(self).__name__} has no weights: call load_state_dict()/from_pretrained() first")
+        if self._device.type != "cuda":
+            raise HipExtensionError(f"{type(self).__name__} runs on hand-written HIP kernels only; call .to('cuda') "
+                                    "(there is no CPU fallback in the MI355X build)")
+        ops.dtype_code(self._dtype)
+        self._w = self._prepare()
+
+    # -- layout helpers --------------------------------------------------------------------------
+    def _kmul(self):
+        return 64 if self._dtype == torch.bfloat16 else 16
+
+    def _act(self, t):
+        return t.to(self._device, self._dtype).contiguous()
+
+    def _f32(self, t):
+        return t.to(self._device, torch.float32).contiguous()
+
+    def _conv3(self, key, cin_pad=None):
+        w = self._raw[key + ".weight"]  # [Cout, Cin, 3, 3]
+        cout, cin = w.shape[0], w.shape[1]
+        cin_pad = cin_pad or cin
+        t = torch.zeros(cout, 3, 3, cin_pad)
+        t[..., :cin] = w.permute(0, 2, 3, 1)
+        return self._act(t.reshape(cout, 9 * cin_pad)), self._f32(self._raw[key + ".bias"])
+
+    def _lin(self, key, bias=True):
+        w = self._raw[key + ".weight"]
+        w = w.reshape(w.shape[0], -1)  # Linear [out,in] or conv1x1 [out,in,1,1]
+        return self._act(w), (self._f32(self._raw[key + ".bias"]) if bias else None)
+
+    def _norm(self, key):
+        return self._f32(self._raw[key + ".weight"]), self._f32(self._raw[key + ".bias"])
+
+
+def composed_attention(q, q_col, ldq, k, k_col, ldk, vt, B, H, d, nq, nk, scale, dtype):
+    """Attention as GEMM -> row softmax -> GEMM (float32 parity path and the d=512 VAE block).
+    q/k: buffers with rows of ldq/ldk elements, head h at columns q_col + h*d; vt: [B, H*d, ldvt] with
+    zero-filled columns >= nk.  Returns [B, nq, H*d]."""
+    es = q.element_size()
+    mul = 64 if dtype == torch.bfloat16 else 4
+    nkp = _pad_to(nk, mul)
+    ldvt = vt.shape[2]
+    if ldvt < nkp:
+        raise HipExtensionError("composed_attention: vt row stride too small")
+    out = torch.empty((B, nq, H * d), dtype=dtype, device=q.device)
+    s = torch.empty((H, nq, nkp), dtype=torch.float32, device=q.device)
+    for b in range(B):
+        ops.gemm_raw(q.data_ptr() + (b * nq * ldq + q_col) * es, k.data_ptr() + (b * nk * ldk + k_col) * es, s.data_ptr(),
+                     dtype, torch.float32, nq, nk, d, ldq, ldk, nkp, batch=H, sA=d, sW=d, sC=nq * nkp)
+        p = ops.softmax_rows(s, nk, scale, dtype, ldp=nkp)
+        ops.gemm_raw(p.data_ptr(), vt.data_ptr() + b * H * d * ldvt * es, out.data_ptr() + b * nq * H * d * es,
+                     dtype, dtype, nq, d, nkp, nkp, ldvt, H * d, batch=H, sA=nq * nkp, sW=d * ldvt, sC=d)
+    return out
+
+
+class UNet2DConditionModel(_HipModule):
+    config_name = "config.json"
+    _defaults = SD15_UNET_DEFAULTS
+
+    def __init__(self, **config):
+        cfg = dict(SD15_UNET_DEFAULTS)
+        unknown = [k for k in config if k not in cfg and not k.startswith("_")]
+        cfg.update({k: v for k, v in config.items() if k in cfg})
+        # generate_hdr.py:103-105 rewrites `num_attention_heads` to the legacy `attention_head_dim` name
+        if "num_attention_heads" in config and config["num_attention_heads"] is not None:
+            cfg["attention_head_dim"] = config["num_attention_heads"]
+        if isinstance(cfg["attention_head_dim"], (list, tuple)):
+            if len(set(cfg["attention_head_dim"])) != 1:
+                raise NotImplementedError("per-block attention_head_dim")
+            cfg["attention_head_dim"] = cfg["attention_head_dim"][0]
+        if cfg["act_fn"] != "silu" or cfg["time_cond_proj_dim"] is not None or cfg["center_input_sample"]:
+            raise NotImplementedError("only the SD-1.5 UNet flavour is implemented (silu, no time_cond_proj, no centering)")
+        self._unknown_config = unknown
+        self.register_to_config(**cfg)
+        self._init_module()
+        self._kv_cache = {}
+        self._t_dev = None
+
+    # ------------------------------------------------------------------------------------------
+    # structure
+    # ------------------------------------------------------------------------------------------
+    def _layout(self):
+        """Yield the block structure shared by expected_keys / _prepare / forward."""
+        c = self.config
+        ch = list(c.block_out_channels)
+        n = c.layers_per_block
+        downs, cout = [], ch[0]
+        for i, t in enumerate(c.down_block_types):
+            cin, cout = cout, ch[i]
+            downs.append(dict(res=[(cin if j == 0 else cout, cout) for j in range(n)], attn=t.startswith("CrossAttn"),
+                              down=i != len(ch) - 1, c=cout))
+        rev = list(reversed(ch))
+        ups, cout = [], rev[0]
+        for i, t in enumerate(c.up_block_types):
+            cprev, cout = cout, rev[i]
+            cin = rev[min(i + 1, len(ch) - 1)]
+            res = []
+            for j in range(n + 1):
+                skip = cin if j == n else cout
+                rin = cprev if j == 0 else cout
+                res.append((rin + skip, cout))
+            ups.append(dict(res=res, attn=t.startswith("CrossAttn"), up=i != len(ch) - 1, c=cout))
+        return downs, ups
+
+    def expected_keys(self):
+        c = self.config
+        ch = list(c.block_out_channels)
+        temb, cross = ch[0] * 4, c.cross_attention_dim
+        keys = {}
+
+        def conv(k, co, ci, ks):
+            keys[k + ".weight"], keys[k + ".bias"] = (co, ci, ks, ks), (co,)
+
+        def lin(k, co, ci, bias=True):
+            keys[k + ".weight"] = (co, ci)
+            if bias:
+                keys[k + ".bias"] = (co,)
+
+        def norm(k, n):
+            keys[k + ".weight"], keys[k + ".bias"] = (n,), (n,)
+
+        def resnet(k, ci, co):
+            norm(k + ".norm1", ci); conv(k + ".conv1", co, ci, 3); lin(k + ".time_emb_proj", co, temb)
+            norm(k + ".norm2", co); conv(k + ".conv2", co, co, 3)
+            if ci != co:
+                conv(k + ".conv_shortcut", co, ci, 1)
+
+        def transformer(k, d):
+            norm(k + ".norm", d); conv(k + ".proj_in", d, d, 1); conv(k + ".proj_out", d, d, 1)
+            b = k + ".transformer_blocks.0"
+            for nm in ("norm1", "norm2", "norm3"):
+                norm(f"{b}.{nm}", d)
+            for a, kd in (("attn1", d), ("attn2", cross)):
+                lin(f"{b}.{a}.to_q", d, d, False); lin(f"{b}.{a}.to_k", d, kd, False); lin(f"{b}.{a}.to_v", d, kd, False)
+                lin(f"{b}.{a}.to_out.0", d, d)
+            lin(f"{b}.ff.net.0.proj", 8 * d, d); lin(f"{b}.ff.net.2", d, 4 * d)
+
+        conv("conv_in", ch[0], c.in_channels, 3)
+        lin("time_embedding.linear_1", temb, ch[0]); lin("time_embedding.linear_2", temb, temb)
+        downs, ups = self._layout()
+        for i, blk in enumerate(downs):
+            for j, (ci, co) in enumerate(blk["res"]):
+                resnet(f"down_blocks.{i}.resnets.{j}", ci, co)
+                if blk["attn"]:
+                    transformer(f"down_blocks.{i}.attentions.{j}", co)
+            if blk["down"]:
+                conv(f"down_blocks.{i}.downsamplers.0.conv", blk["c"], blk["c"], 3)
+        resnet("mid_block.resnets.0", ch[-1], ch[-1]); transformer("mid_block.attentions.0", ch[-1])
+        resnet("mid_block.resnets.1", ch[-1], ch[-1])
+        for i, blk in enumerate(ups):
+            for j, (ci, co) in enumerate(blk["res"]):
+                resnet(f"up_blocks.{i}.resnets.{j}", ci, co)
+                if blk["attn"]:
+                    transformer(f"up_blocks.{i}.attentions.{j}", co)
+            if blk["up"]:
+                conv(f"up_blocks.{i}.upsamplers.0.conv", blk["c"], blk["c"], 3)
+        norm("conv_norm_out", ch[0]); conv("conv_out", c.out_channels, ch[0], 3)
+        return keys
+
+    # ------------------------------------------------------------------------------------------
+    # loading
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **config_overrides):
+        """Read a diffusers-layout directory (``config.json`` + ``diffusion_pytorch_model.safetensors``).
+        Extra kwargs override config entries, as scripts/inference/generate_hdr.py:138-142 does
+        (``in_channels=8, **config``)."""
+        d = os.path.join(path, subfolder) if subfolder else path
+        cfg = cls.load_config(d)
+        cfg.update(config_overrides)
+        m = cls(**cfg)
+        m.load_state_dict(read_state_dict(d))
+        if torch_dtype is not None:
+            m.to(torch_dtype)
+        return m
+
+    def save_pretrained(self, directory):
+        import json
+        from safetensors.torch import save_file
+
+        os.makedirs(directory, exist_ok=True)
+        with open(os.path.join(directory, "config.json"), "w") as f:
+            json.dump({"_class_name": "UNet2DConditionModel", **{k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()}}, f, indent=2)
+        save_file({k: v.contiguous() for k, v in self._raw.items()}, os.path.join(directory, "diffusion_pytorch_model.safetensors"))
+
+    def init_random(self, seed=1234):
+        """Deterministic synthetic weights (uniform +-1/sqrt(fan_in), unit norms) for benchmarks; no checkpoint
+        exists offline."""
+        g = torch.Generator("cpu").manual_seed(seed)
+        sd = {}
+        for k, shp in self.expected_keys().items():
+            if ".norm" in k or k.startswith("conv_norm_out") or k.endswith("norm.weight") or k.endswith("norm.bias"):
+                sd[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+                continue
+            wshape = self.expected_keys()[k.rsplit(".", 1)[0] + ".weight"]
+            fan_in = 1
+            for s_ in wshape[1:]:
+                fan_in *= s_
+            bound = fan_in ** -0.5
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        return self.load_state_dict(sd)
+
+    # ------------------------------------------------------------------------------------------
+    # weight preparation
+    # ------------------------------------------------------------------------------------------
+    def _prepare(self):
+        c = self.config
+        w = {}
+        self._cin_pad = _pad_to(c.in_channels, self._kmul())
+        w["conv_in"] = self._conv3("conv_in", self._cin_pad)
+        w["te1"] = self._lin("time_embedding.linear_1")
+        w["te2"] = self._lin("time_embedding.linear_2")
+
+        def resnet(k):
+            r = dict(n1=self._norm(k + ".norm1"), c1=self._conv3(k + ".conv1"), te=self._lin(k + ".time_emb_proj"),
+                     n2=self._norm(k + ".norm2"), c2=self._conv3(k + ".conv2"))
+            if k + ".conv_shortcut.weight" in self._raw:
+                r["sc"] = self._lin(k + ".conv_shortcut")
+            return r
+
+        def transformer(k):
+            b = k + ".transformer_blocks.0"
+            t = dict(norm=self._norm(k + ".norm"), pin=self._lin(k + ".proj_in"), pout=self._lin(k + ".proj_out"))
+            for nm in ("norm1", "norm2", "norm3"):
+                t[nm] = self._norm(f"{b}.{nm}")
+            q1, k1 = self._raw[f"{b}.attn1.to_q.weight"], self._raw[f"{b}.attn1.to_k.weight"]
+            t["qk1"] = self._act(torch.cat([q1, k1], 0))  # fused [2C, C] projection
+            t["v1"] = self._lin(f"{b}.attn1.to_v", False)[0]
+            t["o1"] = self._lin(f"{b}.attn1.to_out.0")
+            t["q2"] = self._lin(f"{b}.attn2.to_q", False)[0]
+            t["k2"] = self._lin(f"{b}.attn2.to_k", False)[0]
+            t["v2"] = self._lin(f"{b}.attn2.to_v", False)[0]
+            t["o2"] = self._lin(f"{b}.attn2.to_out.0")
+            t["ff1"] = self._lin(f"{b}.ff.net.0.proj")
+            t["ff2"] = self._lin(f"{b}.ff.net.2")
+            t["key"] = k
+            return t
+
+        downs, ups = self._layout()
+        w["down"] = []
+        for i, blk in enumerate(downs):
+            e = dict(res=[resnet(f"down_blocks.{i}.resnets.{j}") for j in range(len(blk["res"]))])
+            if blk["attn"]:
+                e["attn"] = [transformer(f"down_blocks.{i}.attentions.{j}") for j in range(len(blk["res"]))]
+            if blk["down"]:
+                e["ds"] = self._conv3(f"down_blocks.{i}.downsamplers.0.conv")
+            w["down"].append(e)
+        w["mid"] = dict(r0=resnet("mid_block.resnets.0"), a=transformer("mid_block.attentions.0"), r1=resnet("mid_block.resnets.1"))
+        w["up"] = []
+        for i, blk in enumerate(ups):
+            e = dict(res=[resnet(f"up_blocks.{i}.resnets.{j}") for j in range(len(blk["res"]))])
+            if blk["attn"]:
+                e["attn"] = [transformer(f"up_blocks.{i}.attentions.{j}") for j in range(len(blk["res"]))]
+            if blk["up"]:
+                e["us"] = self._conv3(f"up_blocks.{i}.upsamplers.0.conv")
+            w["up"].append(e)
+        w["norm_out"] = self._norm("conv_norm_out")
+        w["conv_out"] = self._conv3("conv_out")
+        self._kv_cache = {}
+        self._t_dev = torch.zeros(1, dtype=torch.float32, device=self._device)
+        return w
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _resnet(self, r, x, B, H, W, temb, eps):
+        G = self.config.norm_num_groups
+        h = ops.groupnorm(x, B, G, r["n1"][0], r["n1"][1], eps, silu=True)
+        tp = ops.gemm_nt(temb, r["te"][0], bias=r["te"][1], out_dtype=torch.float32)
+        h, _, _ = ops.conv3x3(h, r["c1"][0], B, H, W, bias=r["c1"][1], rowbias=tp)
+        h = ops.groupnorm(h, B, G, r["n2"][0], r["n2"][1], eps, silu=True)
+        if "sc" in r:
+            cin = x.shape[-1]
+            x = ops.gemm_nt(x.view(-1, cin), r["sc"][0], bias=r["sc"][1]).view(B, H * W, -1)
+        y, _, _ = ops.conv3x3(h, r["c2"][0], B, H, W, bias=r["c2"][1], residual=x)
+        return y
+
+    def _self_attention(self, t, n1, B, N, C):
+        heads = self.config.attention_head_dim
+        d = C // heads
+        scale = d ** -0.5
+        qk = ops.gemm_nt(n1, t["qk1"]).view(B, N, 2 * C)
+        if self._dtype == torch.bfloat16:
+            vt = ops.gemm_nt(t["v1"], n1.view(B, N, C), ldc=_pad_to(N, 8))  # V^T [B, C, N]
+            return ops.attention(qk, qk, vt, heads, N, scale, k_col=C)
+        npad = _pad_to(N, 4)
+        if npad != N:
+            vt = torch.zeros((B, C, npad), dtype=self._dtype, device=n1.device)
+            ops.gemm_nt(t["v1"], n1.view(B, N, C), out=vt, ldc=npad)
+        else:
+            vt = ops.gemm_nt(t["v1"], n1.view(B, N, C), ldc=npad)
+        return composed_attention(qk, 0, 2 * C, qk, C, 2 * C, vt, B, heads, d, N, N, scale, self._dtype)
+
+    def _cross_kv(self, t, ehs):
+        """K and V^T of the text tokens: constant over the whole denoising loop, so cached per embedding tensor."""
+        key = (t["key"], ehs.data_ptr(), ehs._version, tuple(ehs.shape))
+        hit = self._kv_cache.get(t["key"])
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        B, L, E = ehs.shape
+        C = t["k2"].shape[0]
+        kc = ops.gemm_nt(ehs.view(B * L, E), t["k2"]).view(B, L, C)
+        lpad = _pad_to(L, 8 if self._dtype == torch.bfloat16 else 4)
+        vt = torch.zeros((B, C, lpad), dtype=self._dtype, device=ehs.device)
+        ops.gemm_nt(t["v2"], ehs, out=vt, ldc=lpad)
+        self._kv_cache[t["key"]] = (key, kc, vt, ehs)  # holding `ehs` keeps its address from being recycled
+        return kc, vt
+
+    def _transformer(self, t, x, B, H, W, ehs):
+        C = x.shape[-1]
+        N = H * W
+        heads = self.config.attention_head_dim
+        d = C // heads
+        h = ops.groupnorm(x, B, self.config.norm_num_groups, t["norm"][0], t["norm"][1], 1e-6, silu=False)
+        h = ops.gemm_nt(h.view(B * N, C), t["pin"][0], bias=t["pin"][1])
+        # self-attention
+        n1 = ops.layernorm(h, *t["norm1"])
+        o = self._self_attention(t, n1, B, N, C)
+        h = ops.gemm_nt(o.view(B * N, C), t["o1"][0], bias=t["o1"][1], residual=h)
+        # cross-attention over the text tokens
+        n2 = ops.layernorm(h, *t["norm2"])
+        q = ops.gemm_nt(n2, t["q2"]).view(B, N, C)
+        kc, vtc = self._cross_kv(t, ehs)
+        L = ehs.shape[1]
+        if self._dtype == torch.bfloat16:
+            o = ops.attention(q, kc, vtc, heads, L, d ** -0.5)
+        else:
+            o = composed_attention(q, 0, C, kc, 0, C, vtc, B, heads, d, N, L, d ** -0.5, self._dtype)
+        h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h)
+        # GEGLU feed-forward
+        n3 = ops.layernorm(h, *t["norm3"])
+        f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
+        h = ops.gemm_nt(f, t["ff2"][0], bias=t["ff2"][1], residual=h)
+        return ops.gemm_nt(h, t["pout"][0], bias=t["pout"][1], residual=x.view(B * N, C)).view(B, N, C)
+
+    def set_timestep(self, timestep):
+        """Write the timestep into the device scalar read by the embedding kernel (kept outside any
+        captured graph so the same graph can be replayed for every step)."""
+        self._ensure()
+        t = float(timestep)
+        self._t_dev.copy_(torch.tensor([t], dtype=torch.float32), non_blocking=False)
+
+    def forward_packed(self, x, B, H, W, encoder_hidden_states):
+        """x: packed channels-last input [B, H*W, cin_pad]; the timestep must already be in ``_t_dev``.
+        Returns float32 eps [B, out_channels, H, W].  Stream-ordered, allocation via torch only."""
+        w = self._w
+        c = self.config
+        eps = c.norm_eps
+        ehs = encoder_hidden_states
+        if ehs.dtype != self._dtype:
+            raise HipExtensionError("encoder_hidden_states must already be in the UNet dtype (use prepare_context)")
+        te = ops.timestep_embedding(self._t_dev, B, c.block_out_channels[0], self._dtype, c.flip_sin_to_cos, c.freq_shift)
+        te = ops.gemm_nt(te, w["te1"][0], bias=w["te1"][1], act=ops.ACT_SILU)
+        temb = ops.gemm_nt(te, w["te2"][0], bias=w["te2"][1], act=ops.ACT_SILU)  # = silu(temb): the only use of temb
+        x, _, _ = ops.conv3x3(x, w["conv_in"][0], B, H, W, bias=w["conv_in"][1])
+        skips = [(x, H, W)]
+        for blk in w["down"]:
+            for j, r in enumerate(blk["res"]):
+                x = self._resnet(r, x, B, H, W, temb, eps)
+                if "attn" in blk:
+                    x = self._transformer(blk["attn"][j], x, B, H, W, ehs)
+                skips.append((x, H, W))
+            if "ds" in blk:
+                x, H, W = ops.conv3x3(x, blk["ds"][0], B, H, W, bias=blk["ds"][1], stride=2)
+                skips.append((x, H, W))
+        x = self._resnet(w["mid"]["r0"], x, B, H, W, temb, eps)
+        x = self._transformer(w["mid"]["a"], x, B, H, W, ehs)
+        x = self._resnet(w["mid"]["r1"], x, B, H, W, temb, eps)
+        for blk in w["up"]:
+            for j, r in enumerate(blk["res"]):
+                s, _, _ = skips.pop()
+                x = self._resnet(r, ops.concat_channels(x, s), B, H, W, temb, eps)
+                if "attn" in blk:
+                    x = self._transformer(blk["attn"][j], x, B, H, W, ehs)
+            if "us" in blk:
+                x, H, W = ops.conv3x3(x, blk["us"][0], B, H, W, bias=blk["us"][1], upsample=True)
+        x = ops.groupnorm(x, B, c.norm_num_groups, w["norm_out"][0], w["norm_out"][1], eps, silu=True)
+        y, _, _ = ops.conv3x3(x, w["conv_out"][0], B, H, W, bias=w["conv_out"][1], out_dtype=torch.float32)
+        return ops.unpack_nchw(y, B, c.out_channels, H, W)
+
+    def prepare_context(self, encoder_hidden_states):
+        """Cast text-encoder hidden states to the UNet dtype once (HIP cast kernel)."""
+        self._ensure()
+        ehs = encoder_hidden_states
+        if not ehs.is_cuda:
+            raise HipExtensionError("encoder_hidden_states must be on the HIP device")
+        ehs = ehs.contiguous()
+        if ehs.dtype == self._dtype:
+            return ehs
+        if ehs.dtype not in (torch.float32, torch.bfloat16):
+            ehs = ehs.float()
+        return ops.cast(ehs, self._dtype)
+
+    def pack_input(self, sample, dup=1):
+        """sample: float32 NCHW tensor, or a tuple ``(cond, x)`` concatenated on channels (conditioning first:
+        stable_diffusion_gm.py:1045, dual_unet.py:1080); dup=2 duplicates the batch for CFG (gm.py:1047)."""
+        self._ensure()
+        a, b = (sample if isinstance(sample, (tuple, list)) else (sample, None))
+        if a.dtype != torch.float32:
+            a = ops.cast(a.contiguous(), torch.float32)
+        if b is not None and b.dtype != torch.float32:
+            b = ops.cast(b.contiguous(), torch.float32)
+        nch = a.shape[1] + (0 if b is None else b.shape[1])
+        if nch != self.config.in_channels:
+            raise ValueError(f"UNet expects {self.config.in_channels} input channels, got {nch}")
+        return ops.pack_unet_input(a.contiguous(), None if b is None else b.contiguous(), dup, self._cin_pad, self._dtype)
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
+                 added_cond_kwargs=None, return_dict=True, **kwargs):
+        if timestep_cond is not None or added_cond_kwargs:
+            raise NotImplementedError("timestep_cond / added_cond_kwargs are not part of the SD-1.5 GM-Diffusion path")
+        self._ensure()
+        first = sample[0] if isinstance(sample, (tuple, list)) else sample
+        B, _, H, W = first.shape
+        if H % (2 ** (len(self.config.block_out_channels) - 1)) or W % (2 ** (len(self.config.block_out_channels) - 1)):
+            raise ValueError(f"latent size {H}x{W} must be divisible by {2 ** (len(self.config.block_out_channels) - 1)}")
+        x = self.pack_input(sample)
+        ehs = self.prepare_context(encoder_hidden_states)
+        if ehs.shape[0] != B:
+            raise ValueError(f"encoder_hidden_states batch {ehs.shape[0]} != sample batch {B}")
+        self.set_timestep(timestep)
+        out = self.forward_packed(x, B, H, W, ehs)
+        if not return_dict:
+            return (out,)
+        from .image_processor import UNetOutput
+
+        return UNetOutput(sample=out)
+
+    forward = __call__

@@ -1,0 +1,366 @@
+"""
+Thin torch-tensor front end of the C ABI (include/gmd_hip.h).
+
+torch is used here for device memory and streams only: every function validates
+its operands on the host, allocates the output with ``torch.empty`` and launches
+the hand-written HIP kernel on ``torch.cuda.current_stream()``.  Nothing in this
+module computes with torch ops, and nothing falls back to the CPU: tensors that
+are not on a HIP device raise ``HipExtensionError``.
+
+Activations are channels-last ``[B, H*W, C]`` (or ``[rows, C]``) in bf16 (MFMA path) or
+float32 (parity path); biases / norm parameters / statistics are float32.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._native import ACT_NONE, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
+
+__all__ = [
+    "ACT_NONE", "ACT_SILU", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
+    "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "layernorm", "geglu", "timestep_embedding",
+    "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
+    "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
+]
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return GMD_F32
+    if dt == torch.bfloat16:
+        return GMD_BF16
+    raise HipExtensionError(f"unsupported dtype {dt}: the HIP kernels take float32 or bfloat16")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipExtensionError(
+                "gm_diffusion (MI355X build): tensor is on %s; the compute path is hand-written HIP and has no CPU fallback" % t.device)
+        if not t.is_contiguous():
+            raise HipExtensionError("non-contiguous tensor passed to a HIP kernel")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise HipExtensionError(f"{name} must be float32")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+# dense contractions
+# ----------------------------------------------------------------------------------------------
+def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=1.0, act=ACT_NONE,
+            out_dtype=None, out=None, ldc=None):
+    """``act(alpha * a @ w.T + bias + rowbias[m // rows_per_group] + residual)``.
+
+    a: [M, K] or [batch, M, K]; w: [N, K] or [batch, N, K] (a 2-D operand is shared by the batch)."""
+    _dev(a, w, bias, rowbias, residual, out)
+    if a.dtype != w.dtype:
+        raise HipExtensionError(f"gemm_nt: dtype mismatch {a.dtype} vs {w.dtype}")
+    dt = dtype_code(a.dtype)
+    batch = 1
+    if a.dim() == 3 or w.dim() == 3:
+        batch = a.shape[0] if a.dim() == 3 else w.shape[0]
+    M, K = a.shape[-2], a.shape[-1]
+    N = w.shape[-2]
+    if w.shape[-1] != K:
+        raise HipExtensionError(f"gemm_nt: K mismatch {a.shape} vs {w.shape}")
+    sA = M * K if a.dim() == 3 else 0
+    sW = N * K if w.dim() == 3 else 0
+    out_dtype = out_dtype or a.dtype
+    ldc = ldc or N
+    if out is None:
+        out = torch.empty((batch, M, ldc) if batch > 1 or a.dim() == 3 or w.dim() == 3 else (M, ldc),
+                          dtype=out_dtype, device=a.device)
+    sC = M * ldc
+    sR = 0
+    if residual is not None:
+        if residual.dtype != a.dtype or residual.shape[-1] != N or residual.shape[-2] != M:
+            raise HipExtensionError("gemm_nt: residual must be [M, N] of the input dtype")
+        sR = M * N if residual.dim() == 3 else 0
+    if bias is not None and bias.numel() != N:
+        raise HipExtensionError("gemm_nt: bias must have N elements")
+    check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, dtype_code(out_dtype), M, N, K, K, K, ldc, batch, sA, sW, sC,
+                            _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")), rows_per_group,
+                            _ptr(residual), N, sR, float(alpha), act, _stream()), "gmd_gemm_nt")
+    return out
+
+
+def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, upsample=False, pad_mode=0, out_dtype=None):
+    """x: [B, H*W, Cin]; w: [Cout, 9*Cin] (tap-major); returns ([B, Hout*Wout, Cout], Hout, Wout)."""
+    _dev(x, w, bias, rowbias, residual)
+    cin, cout = x.shape[-1], w.shape[0]
+    if x.numel() != B * H * W * cin or w.shape[1] != 9 * cin or x.dtype != w.dtype:
+        raise HipExtensionError(f"conv3x3: shape/dtype mismatch x={tuple(x.shape)} w={tuple(w.shape)} B,H,W={B},{H},{W}")
+    if upsample:
+        ho, wo = 2 * H, 2 * W
+    elif pad_mode == 1:
+        ho, wo = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
+    else:
+        ho, wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((B, ho * wo, cout), dtype=out_dtype, device=x.device)
+    if residual is not None and (residual.numel() != y.numel() or residual.dtype != x.dtype):
+        raise HipExtensionError("conv3x3: residual shape/dtype mismatch")
+    if rowbias is not None and rowbias.numel() != B * cout:
+        raise HipExtensionError("conv3x3: rowbias must be [B, Cout]")
+    check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, H, W, cin, cout,
+                            stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")),
+                            _ptr(residual), _stream()), "gmd_conv3x3")
+    return y, ho, wo
+
+
+def attention(q, k, vt, heads, nk, scale, k_col=0):
+    """q: [B, Nq, ldq] with Q in columns [0, H*D); k: [B, Nk, ldk] with K in columns [k_col, k_col+H*D)
+    (q and k may be the same fused-projection buffer); vt: [B, H*D, ldvt] (V transposed, keys contiguous)."""
+    _dev(q, k, vt)
+    B, nq = q.shape[0], q.shape[1]
+    hd = vt.shape[1]
+    d = hd // heads
+    ldq, ldk = q.shape[2], k.shape[2]
+    if k.shape[1] < nk or vt.shape[2] < nk or k_col + hd > ldk or hd > ldq:
+        raise HipExtensionError("attention: operand shapes inconsistent")
+    o = torch.empty((B, nq, hd), dtype=q.dtype, device=q.device)
+    check(lib().gmd_attention(_ptr(q), _ptr(k) + k_col * k.element_size(), _ptr(vt), _ptr(o), dtype_code(q.dtype), B, heads, d,
+                              nq, nk, ldq, ldk, vt.shape[2], hd, nq * ldq, k.shape[1] * ldk, hd * vt.shape[2], nq * hd,
+                              float(scale), _stream()), "gmd_attention")
+    return o
+
+
+def softmax_rows(s, cols, scale, out_dtype, ldp=None):
+    _dev(s)
+    _f32(s, "softmax_rows input")
+    lds_ = s.shape[-1]
+    rows = s.numel() // lds_
+    ldp = ldp or lds_
+    p = torch.empty(s.shape[:-1] + (ldp,), dtype=out_dtype, device=s.device)
+    check(lib().gmd_softmax_rows(_ptr(s), lds_, _ptr(p), dtype_code(out_dtype), ldp, rows, cols, float(scale), _stream()),
+          "gmd_softmax_rows")
+    return p
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation / elementwise
+# ----------------------------------------------------------------------------------------------
+def groupnorm_scale_shift(x, B, groups, gamma, beta, eps):
+    """x: [B, HW, C] -> float32 [B, C, 2] = {rstd*gamma, beta - mean*rstd*gamma}."""
+    _dev(x, gamma, beta)
+    C = x.shape[-1]
+    HW = x.numel() // (B * C)
+    nsplit = lib().gmd_groupnorm_nsplit(HW)
+    ws = torch.empty(B * nsplit * groups * 2, dtype=torch.float32, device=x.device)
+    ss = torch.empty((B, C, 2), dtype=torch.float32, device=x.device)
+    check(lib().gmd_groupnorm_stats(_ptr(x), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
+                                    _ptr(_f32(beta, "beta")), _ptr(ws), _ptr(ss), _stream()), "gmd_groupnorm_stats")
+    return ss
+
+
+def groupnorm_apply(x, B, ss, silu):
+    _dev(x, ss)
+    C = x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    check(lib().gmd_groupnorm_apply(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, _ptr(ss), int(silu), _stream()),
+          "gmd_groupnorm_apply")
+    return y
+
+
+def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
+    return groupnorm_apply(x, B, groupnorm_scale_shift(x, B, groups, gamma, beta, eps), silu)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _dev(x, gamma, beta)
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().gmd_layernorm(_ptr(x), _ptr(y), dtype_code(x.dtype), x.numel() // C, C, _ptr(_f32(gamma, "gamma")),
+                              _ptr(_f32(beta, "beta")), float(eps), _stream()), "gmd_layernorm")
+    return y
+
+
+def geglu(x):
+    _dev(x)
+    F2 = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (F2 // 2,), dtype=x.dtype, device=x.device)
+    check(lib().gmd_geglu(_ptr(x), _ptr(y), dtype_code(x.dtype), x.numel() // F2, F2 // 2, _stream()), "gmd_geglu")
+    return y
+
+
+def timestep_embedding(t_dev, B, dim, dtype, flip_sin_to_cos=True, freq_shift=0.0):
+    """t_dev: float32 device scalar (shape [1])."""
+    _dev(t_dev)
+    _f32(t_dev, "timestep")
+    out = torch.empty((B, dim), dtype=dtype, device=t_dev.device)
+    check(lib().gmd_timestep_embedding(_ptr(t_dev), _ptr(out), dtype_code(dtype), B, dim, int(flip_sin_to_cos),
+                                       float(freq_shift), _stream()), "gmd_timestep_embedding")
+    return out
+
+
+def concat_channels(a, b):
+    _dev(a, b)
+    ca, cb = a.shape[-1], b.shape[-1]
+    rows = a.numel() // ca
+    if b.numel() // cb != rows or a.dtype != b.dtype:
+        raise HipExtensionError("concat_channels: row count / dtype mismatch")
+    out = torch.empty(a.shape[:-1] + (ca + cb,), dtype=a.dtype, device=a.device)
+    check(lib().gmd_concat_channels(_ptr(a), ca, _ptr(b), cb, _ptr(out), dtype_code(a.dtype), rows, _stream()),
+          "gmd_concat_channels")
+    return out
+
+
+def cast(x, dtype):
+    _dev(x)
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().gmd_cast(_ptr(x), dtype_code(x.dtype), _ptr(out), dtype_code(dtype), x.numel(), _stream()), "gmd_cast")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# latent-side
+# ----------------------------------------------------------------------------------------------
+def pack_unet_input(src0, src1, dup, cp, dtype):
+    """src0 [B,C0,h,w] (+ src1 [B,C1,h,w]) float32 NCHW -> [dup*B, h*w, cp] channels-last of `dtype`."""
+    _dev(src0, src1)
+    _f32(src0, "src0")
+    _f32(src1, "src1")
+    B, c0 = src0.shape[0], src0.shape[1]
+    hw = src0.shape[2] * src0.shape[3]
+    c1 = 0 if src1 is None else src1.shape[1]
+    out = torch.empty((dup * B, hw, cp), dtype=dtype, device=src0.device)
+    check(lib().gmd_pack_unet_input(_ptr(src0), c0, _ptr(src1), c1, B, hw, dup, _ptr(out), cp, dtype_code(dtype), _stream()),
+          "gmd_pack_unet_input")
+    return out
+
+
+def unpack_nchw(x, B, C, h, w):
+    """x: [B, h*w, ld] -> float32 [B, C, h, w] (first C channels)."""
+    _dev(x)
+    out = torch.empty((B, C, h, w), dtype=torch.float32, device=x.device)
+    check(lib().gmd_unpack_nchw(_ptr(x), dtype_code(x.dtype), x.shape[-1], B, C, h * w, _ptr(out), _stream()), "gmd_unpack_nchw")
+    return out
+
+
+def cfg_std_ratio(eps_pair, guidance_scale):
+    _dev(eps_pair)
+    B = eps_pair.shape[0] // 2
+    ratio = torch.empty(B, dtype=torch.float32, device=eps_pair.device)
+    check(lib().gmd_cfg_std_ratio(_ptr(_f32(eps_pair, "eps")), B, eps_pair[0].numel(), float(guidance_scale), _ptr(ratio), _stream()),
+          "gmd_cfg_std_ratio")
+    return ratio
+
+
+def latent_step(eps_in, x, mode, coefs, do_cfg, guidance_scale, cur_sample=None, hist=(), ratio=None,
+                guidance_rescale=0.0, want_x0=False):
+    """Fused CFG + x0 + PLMS update.  coefs = (sample_coeff, alpha_delta, denom, sqrt_alpha, sqrt_one_minus_alpha).
+    Returns (eps, x_prev, x0|None)."""
+    _dev(eps_in, x, cur_sample, ratio, *hist)
+    for t in (eps_in, x, cur_sample, *hist):
+        _f32(t, "latent tensors")
+    B = x.shape[0]
+    chw = x[0].numel()
+    eps_out = torch.empty_like(x)
+    x_prev = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    h = list(hist) + [None] * (3 - len(hist))
+    sc, ad, dn, sa, s1 = (float(c) for c in coefs)
+    check(lib().gmd_latent_step(_ptr(eps_in), _ptr(x), _ptr(cur_sample), _ptr(h[0]), _ptr(h[1]), _ptr(h[2]), B, chw,
+                                int(do_cfg), float(guidance_scale), _ptr(ratio), float(guidance_rescale), mode,
+                                sc, ad, dn, sa, s1, _ptr(eps_out), _ptr(x_prev), _ptr(x0), _stream()), "gmd_latent_step")
+    return eps_out, x_prev, x0
+
+
+# ----------------------------------------------------------------------------------------------
+# HDR tail
+# ----------------------------------------------------------------------------------------------
+def hdr_tail(sdr_dec, gm_dec, layout, B, H, W, qmax=99.0, eps=1 / 64, clamp=False,
+             want=("sdr", "gm", "sdr_u8", "gm_u8", "hdr", "hdr_file", "hdr_u16")):
+    """layout 0: [B,3,H,W]; 1: [B,H*W,3]; 2: [B,H*W,4].  Returns dict of [B,H,W,3] tensors."""
+    _dev(sdr_dec, gm_dec)
+    if sdr_dec.dtype != gm_dec.dtype:
+        raise HipExtensionError("hdr_tail: dtype mismatch")
+    dev = sdr_dec.device
+    shp = (B, H, W, 3)
+    kinds = {"sdr": torch.float32, "gm": torch.float32, "sdr_u8": torch.uint8, "gm_u8": torch.uint8,
+             "hdr": torch.float32, "hdr_file": torch.float32, "hdr_u16": torch.uint16}
+    out = {k: torch.empty(shp, dtype=kinds[k], device=dev) for k in want}
+    g = lambda k: _ptr(out.get(k))
+    check(lib().gmd_hdr_tail(_ptr(sdr_dec), _ptr(gm_dec), dtype_code(sdr_dec.dtype), layout, B, H, W, float(qmax), float(eps),
+                             1 if clamp else 0, g("sdr"), g("gm"), g("sdr_u8"), g("gm_u8"), g("hdr"), g("hdr_file"),
+                             g("hdr_u16"), _stream()), "gmd_hdr_tail")
+    return out
+
+
+def apply_gm_to_sdr(gm, sdr, qmax=9, eps=1 / 64, clamp=True):
+    _dev(gm, sdr)
+    gm, sdr = torch.broadcast_tensors(gm, sdr)
+    gm, sdr = _f32(gm.contiguous(), "gm"), _f32(sdr.contiguous(), "sdr")
+    out = torch.empty_like(sdr)
+    check(lib().gmd_apply_gm_to_sdr(_ptr(gm), _ptr(sdr), _ptr(out), sdr.numel(), float(qmax), float(eps), int(clamp), _stream()),
+          "gmd_apply_gm_to_sdr")
+    return out
+
+
+def tmo(x, kind, qmax=0.0, mu=500.0):
+    _dev(x)
+    _f32(x, "tmo input")
+    out = torch.empty_like(x)
+    check(lib().gmd_tmo(_ptr(x), _ptr(out), x.numel(), kind, float(qmax), float(mu), _stream()), "gmd_tmo")
+    return out
+
+
+def gamut_compress(x):
+    _dev(x)
+    _f32(x, "gamut_compress input")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise HipExtensionError("gamut_compress expects (B, 3, H, W)")
+    out = torch.empty_like(x)
+    check(lib().gmd_gamut_compress(_ptr(x), _ptr(out), x.shape[0], x.shape[2] * x.shape[3], _stream()), "gmd_gamut_compress")
+    return out
+
+
+def stage1_chain(gm, sdr, qmax):
+    _dev(gm, sdr)
+    _f32(gm, "gm")
+    _f32(sdr, "sdr")
+    out = torch.empty_like(sdr)
+    check(lib().gmd_stage1_chain(_ptr(gm), _ptr(sdr), _ptr(out), sdr.shape[0], sdr.shape[2] * sdr.shape[3], float(qmax), _stream()),
+          "gmd_stage1_chain")
+    return out
+
+
+def discretize_u16(x, codes=False):
+    _dev(x)
+    _f32(x, "discretize input")
+    outf = torch.empty_like(x)
+    outc = torch.empty(x.shape, dtype=torch.uint16, device=x.device) if codes else None
+    check(lib().gmd_discretize_u16(_ptr(x), _ptr(outf), _ptr(outc), x.numel(), _stream()), "gmd_discretize_u16")
+    return (outf, outc) if codes else outf
+
+
+def quantize_u8(x):
+    _dev(x)
+    _f32(x, "quantize input")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib().gmd_quantize_u8(_ptr(x), _ptr(out), x.numel(), _stream()), "gmd_quantize_u8")
+    return out
+
+
+def gemm_raw(a_ptr, w_ptr, c_ptr, dtype, out_dtype, M, N, K, lda, ldw, ldc, batch=1, sA=0, sW=0, sC=0,
+             bias=None, alpha=1.0, act=ACT_NONE):
+    """Pointer-level gmd_gemm_nt for strided sub-blocks (per-head attention products of the parity path).
+    a_ptr/w_ptr/c_ptr are integer device addresses; the caller keeps the owning tensors alive."""
+    _dev(bias)
+    check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, dtype_code(dtype), dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
+                            sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, None, 0, 0, float(alpha), act, _stream()),
+          "gmd_gemm_nt")

@@ -1,0 +1,174 @@
+"""
+``StableDiffusionDualUNetPipeline`` -- the Stage-3 text->HDR path: an SDR UNet (with
+classifier-free guidance) and a GM UNet (conditional only, fed the SDR x0-prediction) are stepped
+jointly with two scheduler instances.  Drop-in mirror of the reference class at
+gm_diffusion/pipelines/stable_diffusion_dual_unet.py:156 (constructor :202-214, ``__call__``
+:782-1140).
+
+Per iteration (reference lines):
+  1045-1060  SDR UNet on cat([latents]*2)                      -> pack kernel (CFG duplicate) + HIP UNet
+  1063-1069  CFG combine (+ rescale_noise_cfg)                 \\
+  1071-1075  x0 = (x - sqrt(1-a) eps) / sqrt(a)                  > ONE fused HIP kernel (gmd_latent_step)
+  1077       latents = scheduler.step(eps, t, latents)         /
+  1080       gm_in = cat([x0, gm_latents], dim=1)              -> folded into the GM UNet input pack
+  1083-1092  GM UNet on gm_in with the conditional embeddings  -> HIP UNet
+  1093       gm_latents = gm_scheduler.step(...)               -> gmd_latent_step (no CFG)
+
+Generalisations over the reference as written: the GM UNet receives the
+conditional half ``prompt_embeds[negative.shape[0]:]`` (scripts/inference/experiments/
+visualize_latents.py:274), which equals the reference's ``prompt_embeds[1:]`` for its only working
+case (batch 1 + CFG) and also works for batch > 1 and without CFG; with a non-latent
+``output_type`` BOTH latents are decoded (the reference decodes neither correctly,
+dual_unet.py:1117-1132).  As in the reference the result is always the bare tuple
+``(sdr, gm)`` and ``return_dict`` is ignored (:1132); ``callback_on_step_end`` is accepted and
+ignored (:1095-1103 is commented out there).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import torch
+
+from .stable_diffusion_gm import _GMPipelineBase, rescale_noise_cfg, retrieve_timesteps
+
+__all__ = ["StableDiffusionDualUNetPipeline", "rescale_noise_cfg", "retrieve_timesteps"]
+
+
+class StableDiffusionDualUNetPipeline(_GMPipelineBase):
+    def __init__(self, vae, text_encoder, tokenizer, unet, gm_unet, scheduler, safety_checker, feature_extractor,
+                 image_encoder=None, requires_safety_checker: bool = True):
+        self._init_common(vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor, image_encoder,
+                          requires_safety_checker, gm_unet=gm_unet)
+
+    @torch.no_grad()
+    def __call__(
+        self,
+        prompt: Union[str, List[str]] = None,
+        height: Optional[int] = None,
+        width: Optional[int] = None,
+        num_inference_steps: int = 50,
+        timesteps: List[int] = None,
+        sigmas: List[float] = None,
+        guidance_scale: float = 7.5,
+        negative_prompt: Optional[Union[str, List[str]]] = None,
+        num_images_per_prompt: Optional[int] = 1,
+        eta: float = 0.0,
+        generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+        latents: Optional[torch.Tensor] = None,
+        prompt_embeds: Optional[torch.Tensor] = None,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        ip_adapter_image=None,
+        ip_adapter_image_embeds: Optional[List[torch.Tensor]] = None,
+        output_type: Optional[str] = "pil",
+        return_dict: bool = True,
+        cross_attention_kwargs: Optional[Dict[str, Any]] = None,
+        guidance_rescale: float = 0.0,
+        clip_skip: Optional[int] = None,
+        callback_on_step_end: Optional[Callable[[Any, int, Any, Dict], Dict]] = None,
+        callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+        **kwargs,
+    ):
+        callback, callback_steps = self._pop_legacy_callbacks(kwargs)
+        if hasattr(callback_on_step_end, "tensor_inputs"):
+            callback_on_step_end_tensor_inputs = callback_on_step_end.tensor_inputs
+        height, width = self._default_hw(height, width)
+        self.check_inputs(prompt, height, width, callback_steps, negative_prompt, prompt_embeds, negative_prompt_embeds,
+                          ip_adapter_image, ip_adapter_image_embeds, callback_on_step_end_tensor_inputs)
+        self._guidance_scale = guidance_scale
+        self._guidance_rescale = guidance_rescale
+        self._clip_skip = clip_skip
+        self._cross_attention_kwargs = cross_attention_kwargs
+        self._interrupt = False
+
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        device = self._execution_device
+        lora_scale = self.cross_attention_kwargs.get("scale", None) if self.cross_attention_kwargs is not None else None
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, device, num_images_per_prompt, self.do_classifier_free_guidance, negative_prompt,
+            prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, lora_scale=lora_scale,
+            clip_skip=self.clip_skip)
+        do_cfg = self.do_classifier_free_guidance
+        n_neg = negative_prompt_embeds.shape[0] if do_cfg else 0
+        if do_cfg:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
+        gm_prompt_embeds = prompt_embeds[n_neg:]  # conditional half (vis.py:274)
+
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, sigmas)
+
+        num_channels_latents = self.unet.config.in_channels
+        latents = self.prepare_latents(batch_size * num_images_per_prompt, num_channels_latents, height, width,
+                                       self._latent_dtype(prompt_embeds, device), device, generator, latents)
+        gm_latents = latents.clone()  # dual.py:1012: both streams start from the same (scaled) noise
+        extra_step_kwargs = self.prepare_extra_step_kwargs(generator, eta)
+
+        num_warmup_steps = len(timesteps) - num_inference_steps * self.scheduler.order
+        self._num_timesteps = len(timesteps)
+        self.gm_scheduler = copy.deepcopy(self.scheduler)  # dual.py:1037, after set_timesteps
+
+        fused = self._use_fused(latents, self.unet, self.scheduler) and self._use_fused(latents, self.gm_unet, self.gm_scheduler)
+        if fused:
+            ctx = self.unet.prepare_context(prompt_embeds)
+            gm_ctx = self.gm_unet.prepare_context(gm_prompt_embeds)
+            h, w = latents.shape[-2:]
+
+        with self.progress_bar(total=num_inference_steps) as progress_bar:
+            for i, t in enumerate(timesteps):
+                if self.interrupt:
+                    continue
+                if fused:
+                    x = self.unet.pack_input(latents, dup=2 if do_cfg else 1)
+                    self.unet.set_timestep(t)
+                    sdr_noise_pred = self.unet.forward_packed(x, x.shape[0], h, w, ctx)
+                    pre_step = latents
+                    latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, t, pre_step, do_cfg, self.guidance_scale,
+                                                                   self.guidance_rescale if do_cfg else 0.0, want_x0=True)
+                    gx = self.gm_unet.pack_input((x0_latent, gm_latents), dup=1)
+                    self.gm_unet.set_timestep(t)
+                    gm_noise_pred = self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
+                    gm_latents = self.gm_scheduler.step(gm_noise_pred, t, gm_latents, return_dict=False)[0]
+                else:
+                    latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
+                    latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+                    gm_latents = self.gm_scheduler.scale_model_input(gm_latents, t)
+                    sdr_noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, timestep_cond=None,
+                                               cross_attention_kwargs=self.cross_attention_kwargs, added_cond_kwargs=None,
+                                               return_dict=False)[0]
+                    if do_cfg:
+                        sdr_noise_pred_uncond, sdr_noise_pred_text = sdr_noise_pred.chunk(2)
+                        sdr_noise_pred = sdr_noise_pred_uncond + self.guidance_scale * (sdr_noise_pred_text - sdr_noise_pred_uncond)
+                    if do_cfg and self.guidance_rescale > 0.0:
+                        sdr_noise_pred = rescale_noise_cfg(sdr_noise_pred, sdr_noise_pred_text, guidance_rescale=self.guidance_rescale)
+                    # x0-prediction (dual.py:1071-1075), from the PRE-step latents
+                    alphas_cumprod = self.scheduler.alphas_cumprod.to(sdr_noise_pred.device)[t].view(-1, 1, 1, 1)
+                    sqrt_alpha_cumprod = alphas_cumprod.sqrt()
+                    sqrt_one_minus_alpha_cumprod = (1 - alphas_cumprod).sqrt()
+                    x0_latent = (latents - sqrt_one_minus_alpha_cumprod * sdr_noise_pred) / sqrt_alpha_cumprod
+                    latents = self.scheduler.step(sdr_noise_pred, t, latents, **extra_step_kwargs, return_dict=False)[0]
+                    gm_latent_input = torch.cat([x0_latent, gm_latents], dim=1)
+                    gm_noise_pred = self.gm_unet(gm_latent_input, t, encoder_hidden_states=gm_prompt_embeds, timestep_cond=None,
+                                                 cross_attention_kwargs=self.cross_attention_kwargs, added_cond_kwargs=None,
+                                                 return_dict=False)[0]
+                    gm_latents = self.gm_scheduler.step(gm_noise_pred, t, gm_latents, **extra_step_kwargs, return_dict=False)[0]
+
+                if i == len(timesteps) - 1 or ((i + 1) > num_warmup_steps and (i + 1) % self.scheduler.order == 0):
+                    progress_bar.update()
+                    if callback is not None and i % callback_steps == 0:
+                        step_idx = i // getattr(self.scheduler, "order", 1)
+                        callback(step_idx, t, latents)
+
+        if output_type == "latent":
+            return (latents, gm_latents)
+        sf = self.vae.config.scaling_factor
+        sdr_image = self.vae.decode(latents / sf, return_dict=False, generator=generator)[0]
+        gm_image = self.vae.decode(gm_latents / sf, return_dict=False, generator=generator)[0]
+        do_denormalize = [True] * sdr_image.shape[0]
+        sdr_out = self.image_processor.postprocess(sdr_image, output_type=output_type, do_denormalize=do_denormalize)
+        gm_out = self.image_processor.postprocess(gm_image, output_type=output_type, do_denormalize=do_denormalize)
+        self.maybe_free_model_hooks()
+        return (sdr_out, gm_out)

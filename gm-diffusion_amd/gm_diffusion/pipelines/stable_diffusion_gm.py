@@ -1,0 +1,462 @@
+"""
+``StableDiffusionGMPipeline`` -- single 8-channel UNet that denoises the gain-map (GM) latent
+conditioned on a given SDR latent.  Drop-in mirror of the reference class at
+gm_diffusion/pipelines/stable_diffusion_gm.py:156 (constructor :202-213, ``__call__`` :780-1114):
+same argument names, defaults, return types and errors.  The orchestration is host Python as in
+the reference; what runs underneath is the MI355X path:
+
+  * ``unet`` / ``vae`` are ``gm_diffusion.components`` models on hand-written HIP kernels;
+  * with a ``PNDMScheduler`` and device tensors the per-step glue -- CFG combine, guidance
+    rescale, PLMS update (:1062-1071) -- is ONE fused HIP kernel (``gmd_latent_step``) and the
+    8-channel concat + CFG duplicate (:1045-1047) is folded into the UNet input pack kernel;
+  * any other scheduler, or host tensors with a duck-typed UNet, takes the generic protocol path
+    that executes the reference's torch expressions verbatim.
+
+Behaviour notes kept from the reference: the latent channel count is forced to 4 and the latent
+size is taken from ``sdr_latent`` (:1003-1015, ``height``/``width`` are ignored); unknown
+``**kwargs`` are ignored (callers pass ``noise_level=``); per-call state lives on ``self``
+(not re-entrant).  LoRA / textual-inversion / IP-adapter mixins of the diffusers base are not
+part of this path: ``cross_attention_kwargs['scale']`` is accepted and ignored, ``ip_adapter_*``
+raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import inspect
+import logging
+import warnings
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import torch
+
+from ..components.configuration import FrozenDict
+from ..components.image_processor import StableDiffusionPipelineOutput, VaeImageProcessor, randn_tensor
+from ..components.schedulers import PNDMScheduler
+from .pipeline_utils import DiffusionPipeline
+
+logger = logging.getLogger(__name__)
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """Reference: stable_diffusion_gm.py:71-94 (Section 3.4 of arXiv:2305.08891)."""
+    std_text = noise_pred_text.std(dim=list(range(1, noise_pred_text.ndim)), keepdim=True)
+    std_cfg = noise_cfg.std(dim=list(range(1, noise_cfg.ndim)), keepdim=True)
+    noise_pred_rescaled = noise_cfg * (std_text / std_cfg)
+    noise_cfg = guidance_rescale * noise_pred_rescaled + (1 - guidance_rescale) * noise_cfg
+    return noise_cfg
+
+
+def retrieve_timesteps(scheduler, num_inference_steps: Optional[int] = None, device=None,
+                       timesteps: Optional[List[int]] = None, sigmas: Optional[List[float]] = None, **kwargs):
+    """Reference: stable_diffusion_gm.py:97-153."""
+    if timesteps is not None and sigmas is not None:
+        raise ValueError("Only one of `timesteps` or `sigmas` can be passed. Please choose one to set custom values")
+    if timesteps is not None:
+        if "timesteps" not in set(inspect.signature(scheduler.set_timesteps).parameters.keys()):
+            raise ValueError(
+                f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
+                f" timestep schedules. Please check whether you are using the correct scheduler.")
+        scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
+        timesteps = scheduler.timesteps
+        num_inference_steps = len(timesteps)
+    elif sigmas is not None:
+        if "sigmas" not in set(inspect.signature(scheduler.set_timesteps).parameters.keys()):
+            raise ValueError(
+                f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
+                f" sigmas schedules. Please check whether you are using the correct scheduler.")
+        scheduler.set_timesteps(sigmas=sigmas, device=device, **kwargs)
+        timesteps = scheduler.timesteps
+        num_inference_steps = len(timesteps)
+    else:
+        scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+        timesteps = scheduler.timesteps
+    return timesteps, num_inference_steps
+
+
+class _GMPipelineBase(DiffusionPipeline):
+    """Everything the GM and dual-UNet pipelines share (the reference duplicates it in three files)."""
+
+    model_cpu_offload_seq = "text_encoder->image_encoder->unet->vae"
+    _optional_components = ["safety_checker", "feature_extractor", "image_encoder"]
+    _exclude_from_cpu_offload = ["safety_checker"]
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
+
+    def _init_common(self, vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor,
+                     image_encoder, requires_safety_checker, **extra_modules):
+        DiffusionPipeline.__init__(self)
+        # stable_diffusion_gm.py:216-241: patch outdated scheduler configs
+        if scheduler is not None and getattr(scheduler.config, "steps_offset", 1) != 1:
+            warnings.warn(f"The configuration file of this scheduler: {scheduler} is outdated. `steps_offset` should be set to 1 "
+                          f"instead of {scheduler.config.steps_offset}.", FutureWarning)
+            new_config = dict(scheduler.config)
+            new_config["steps_offset"] = 1
+            scheduler._internal_dict = FrozenDict(new_config)
+        if scheduler is not None and getattr(scheduler.config, "clip_sample", False) is True:
+            warnings.warn(f"The configuration file of this scheduler: {scheduler} has not set the configuration `clip_sample`. "
+                          "`clip_sample` should be set to False.", FutureWarning)
+            new_config = dict(scheduler.config)
+            new_config["clip_sample"] = False
+            scheduler._internal_dict = FrozenDict(new_config)
+        if safety_checker is None and requires_safety_checker:
+            logger.warning(f"You have disabled the safety checker for {self.__class__} by passing `safety_checker=None`.")
+        if safety_checker is not None and feature_extractor is None:
+            raise ValueError("Make sure to define a feature extractor when loading {self.__class__} if you want to use the safety"
+                             " checker. If you do not want to use the safety checker, you can pass `'safety_checker=None'` instead.")
+        self._is_unet_config_sample_size_int = unet is not None and isinstance(unet.config.sample_size, int)
+        modules = dict(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet)
+        modules.update(extra_modules)
+        modules.update(scheduler=scheduler, safety_checker=safety_checker, feature_extractor=feature_extractor,
+                       image_encoder=image_encoder)
+        self.register_modules(**modules)
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1) if getattr(self, "vae", None) else 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
+        self.register_to_config(requires_safety_checker=requires_safety_checker)
+
+    # ---- prompt encoding (stable_diffusion_gm.py:334-514) ---------------------------------------
+    def encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt=None,
+                      prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                      lora_scale: Optional[float] = None, clip_skip: Optional[int] = None):
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+
+        if prompt_embeds is None:
+            text_inputs = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                         truncation=True, return_tensors="pt")
+            text_input_ids = text_inputs.input_ids
+            untruncated_ids = self.tokenizer(prompt, padding="longest", return_tensors="pt").input_ids
+            if untruncated_ids.shape[-1] >= text_input_ids.shape[-1] and not torch.equal(text_input_ids, untruncated_ids):
+                removed_text = self.tokenizer.batch_decode(untruncated_ids[:, self.tokenizer.model_max_length - 1: -1])
+                logger.warning("The following part of your input was truncated because CLIP can only handle sequences up to"
+                               f" {self.tokenizer.model_max_length} tokens: {removed_text}")
+            if hasattr(self.text_encoder.config, "use_attention_mask") and self.text_encoder.config.use_attention_mask:
+                attention_mask = text_inputs.attention_mask.to(device)
+            else:
+                attention_mask = None
+            if clip_skip is None:
+                prompt_embeds = self.text_encoder(text_input_ids.to(device), attention_mask=attention_mask)
+                prompt_embeds = prompt_embeds[0]
+            else:
+                prompt_embeds = self.text_encoder(text_input_ids.to(device), attention_mask=attention_mask, output_hidden_states=True)
+                prompt_embeds = prompt_embeds[-1][-(clip_skip + 1)]
+                prompt_embeds = self.text_encoder.text_model.final_layer_norm(prompt_embeds)
+
+        if self.text_encoder is not None:
+            prompt_embeds_dtype = self.text_encoder.dtype
+        elif self.unet is not None:
+            prompt_embeds_dtype = self.unet.dtype
+        else:
+            prompt_embeds_dtype = prompt_embeds.dtype
+        prompt_embeds = prompt_embeds.to(dtype=prompt_embeds_dtype, device=device)
+
+        bs_embed, seq_len, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1)
+        prompt_embeds = prompt_embeds.view(bs_embed * num_images_per_prompt, seq_len, -1)
+
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            uncond_tokens: List[str]
+            if negative_prompt is None:
+                uncond_tokens = [""] * batch_size
+            elif prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")
+            elif isinstance(negative_prompt, str):
+                uncond_tokens = [negative_prompt]
+            elif batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                                 f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                                 " the batch size of `prompt`.")
+            else:
+                uncond_tokens = negative_prompt
+            max_length = prompt_embeds.shape[1]
+            uncond_input = self.tokenizer(uncond_tokens, padding="max_length", max_length=max_length, truncation=True,
+                                          return_tensors="pt")
+            if hasattr(self.text_encoder.config, "use_attention_mask") and self.text_encoder.config.use_attention_mask:
+                attention_mask = uncond_input.attention_mask.to(device)
+            else:
+                attention_mask = None
+            negative_prompt_embeds = self.text_encoder(uncond_input.input_ids.to(device), attention_mask=attention_mask)
+            negative_prompt_embeds = negative_prompt_embeds[0]
+
+        if do_classifier_free_guidance:
+            seq_len = negative_prompt_embeds.shape[1]
+            negative_prompt_embeds = negative_prompt_embeds.to(dtype=prompt_embeds_dtype, device=device)
+            negative_prompt_embeds = negative_prompt_embeds.repeat(1, num_images_per_prompt, 1)
+            negative_prompt_embeds = negative_prompt_embeds.view(batch_size * num_images_per_prompt, seq_len, -1)
+        return prompt_embeds, negative_prompt_embeds
+
+    def _encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt=None,
+                       prompt_embeds=None, negative_prompt_embeds=None, lora_scale=None, **kwargs):
+        """Deprecated concatenated form (stable_diffusion_gm.py:302-332)."""
+        t = self.encode_prompt(prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt,
+                               prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, lora_scale=lora_scale, **kwargs)
+        return torch.cat([t[1], t[0]])
+
+    def run_safety_checker(self, image, device, dtype):
+        if self.safety_checker is None:
+            return image, None
+        raise NotImplementedError("the safety checker is outside the GM-Diffusion hot path; pass safety_checker=None")
+
+    def decode_latents(self, latents):
+        """Deprecated helper (stable_diffusion_gm.py:599-608)."""
+        latents = 1 / self.vae.config.scaling_factor * latents
+        image = self.vae.decode(latents, return_dict=False)[0]
+        image = self.image_processor.denormalize(image)
+        return image.cpu().permute(0, 2, 3, 1).float().numpy()
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """stable_diffusion_gm.py:610-625"""
+        params = set(inspect.signature(self.scheduler.step).parameters.keys())
+        extra = {}
+        if "eta" in params:
+            extra["eta"] = eta
+        if "generator" in params:
+            extra["generator"] = generator
+        return extra
+
+    def check_inputs(self, prompt, height, width, callback_steps, negative_prompt=None, prompt_embeds=None,
+                     negative_prompt_embeds=None, ip_adapter_image=None, ip_adapter_image_embeds=None,
+                     callback_on_step_end_tensor_inputs=None):
+        """stable_diffusion_gm.py:627-694"""
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type"
+                             f" {type(callback_steps)}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(
+                k in self._callback_tensor_inputs for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found "
+                             f"{[k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                             " only forward one of the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        elif prompt is not None and (not isinstance(prompt, str) and not isinstance(prompt, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `negative_prompt`: {negative_prompt} and `negative_prompt_embeds`:"
+                             f" {negative_prompt_embeds}. Please make sure to only forward one of the two.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None:
+            if prompt_embeds.shape != negative_prompt_embeds.shape:
+                raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
+                                 f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds`"
+                                 f" {negative_prompt_embeds.shape}.")
+        if ip_adapter_image is not None and ip_adapter_image_embeds is not None:
+            raise ValueError("Provide either `ip_adapter_image` or `ip_adapter_image_embeds`. Cannot leave both `ip_adapter_image`"
+                             " and `ip_adapter_image_embeds` defined.")
+        if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
+            raise NotImplementedError("IP-Adapter conditioning is not part of the GM-Diffusion hot path")
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        """stable_diffusion_gm.py:696-716"""
+        shape = (batch_size, num_channels_latents, int(height) // self.vae_scale_factor, int(width) // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        latents = latents * self.scheduler.init_noise_sigma
+        return latents
+
+    # ---- properties (stable_diffusion_gm.py:749-778) ---------------------------------------------
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def guidance_rescale(self):
+        return self._guidance_rescale
+
+    @property
+    def clip_skip(self):
+        return self._clip_skip
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1 and self.unet.config.time_cond_proj_dim is None
+
+    @property
+    def cross_attention_kwargs(self):
+        return self._cross_attention_kwargs
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    # ---- shared pieces of __call__ -------------------------------------------------------------
+    def _latent_dtype(self, prompt_embeds, device):
+        """Latents, scheduler state, CFG and x0 stay float32 on the HIP path (the documented cast point of the
+        bf16 configuration: the UNet casts while packing its input); host tensors keep the reference's choice."""
+        return torch.float32 if torch.device(device).type == "cuda" else prompt_embeds.dtype
+
+    def _use_fused(self, latents, unet, scheduler):
+        from ..components.unet_2d_condition import UNet2DConditionModel
+
+        return latents.is_cuda and isinstance(scheduler, PNDMScheduler) and isinstance(unet, UNet2DConditionModel)
+
+    def _default_hw(self, height, width):
+        if not height or not width:
+            height = self.unet.config.sample_size if self._is_unet_config_sample_size_int else self.unet.config.sample_size[0]
+            width = self.unet.config.sample_size if self._is_unet_config_sample_size_int else self.unet.config.sample_size[1]
+            height, width = height * self.vae_scale_factor, width * self.vae_scale_factor
+        return height, width
+
+    @staticmethod
+    def _pop_legacy_callbacks(kwargs):
+        callback = kwargs.pop("callback", None)
+        callback_steps = kwargs.pop("callback_steps", None)
+        if callback is not None:
+            warnings.warn("Passing `callback` as an input argument to `__call__` is deprecated, consider using `callback_on_step_end`", FutureWarning)
+        if callback_steps is not None:
+            warnings.warn("Passing `callback_steps` as an input argument to `__call__` is deprecated, consider using `callback_on_step_end`", FutureWarning)
+        return callback, callback_steps
+
+
+class StableDiffusionGMPipeline(_GMPipelineBase):
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor,
+                 image_encoder=None, requires_safety_checker: bool = True):
+        self._init_common(vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor, image_encoder,
+                          requires_safety_checker)
+
+    @torch.no_grad()
+    def __call__(
+        self,
+        sdr_latent: torch.Tensor,
+        prompt: Union[str, List[str]] = None,
+        height: Optional[int] = None,
+        width: Optional[int] = None,
+        num_inference_steps: int = 50,
+        timesteps: List[int] = None,
+        sigmas: List[float] = None,
+        guidance_scale: float = 7.5,
+        negative_prompt: Optional[Union[str, List[str]]] = None,
+        num_images_per_prompt: Optional[int] = 1,
+        eta: float = 0.0,
+        generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+        latents: Optional[torch.Tensor] = None,
+        prompt_embeds: Optional[torch.Tensor] = None,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        ip_adapter_image=None,
+        ip_adapter_image_embeds: Optional[List[torch.Tensor]] = None,
+        output_type: Optional[str] = "pil",
+        return_dict: bool = True,
+        cross_attention_kwargs: Optional[Dict[str, Any]] = None,
+        guidance_rescale: float = 0.0,
+        clip_skip: Optional[int] = None,
+        callback_on_step_end: Optional[Callable[[Any, int, Any, Dict], Dict]] = None,
+        callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+        **kwargs,
+    ):
+        callback, callback_steps = self._pop_legacy_callbacks(kwargs)
+        if hasattr(callback_on_step_end, "tensor_inputs"):
+            callback_on_step_end_tensor_inputs = callback_on_step_end.tensor_inputs
+
+        height, width = self._default_hw(height, width)
+        self.check_inputs(prompt, height, width, callback_steps, negative_prompt, prompt_embeds, negative_prompt_embeds,
+                          ip_adapter_image, ip_adapter_image_embeds, callback_on_step_end_tensor_inputs)
+        self._guidance_scale = guidance_scale
+        self._guidance_rescale = guidance_rescale
+        self._clip_skip = clip_skip
+        self._cross_attention_kwargs = cross_attention_kwargs
+        self._interrupt = False
+
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        device = self._execution_device
+        lora_scale = self.cross_attention_kwargs.get("scale", None) if self.cross_attention_kwargs is not None else None
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, device, num_images_per_prompt, self.do_classifier_free_guidance, negative_prompt,
+            prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, lora_scale=lora_scale,
+            clip_skip=self.clip_skip)
+        if self.do_classifier_free_guidance:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
+
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps, sigmas)
+
+        # gm.py:1003-1015: latent channels forced to 4, latent size taken from sdr_latent
+        num_channels_latents = 4
+        latents = self.prepare_latents(batch_size * num_images_per_prompt, num_channels_latents, sdr_latent.shape[-2] * 8,
+                                       sdr_latent.shape[-1] * 8, self._latent_dtype(prompt_embeds, device), device, generator, latents)
+        extra_step_kwargs = self.prepare_extra_step_kwargs(generator, eta)
+
+        num_warmup_steps = len(timesteps) - num_inference_steps * self.scheduler.order
+        self._num_timesteps = len(timesteps)
+        do_cfg = self.do_classifier_free_guidance
+        fused = self._use_fused(latents, self.unet, self.scheduler)
+        if fused:
+            ctx = self.unet.prepare_context(prompt_embeds)
+            sdr_f32 = sdr_latent.to(device=latents.device, dtype=torch.float32).contiguous()
+
+        with self.progress_bar(total=num_inference_steps) as progress_bar:
+            for i, t in enumerate(timesteps):
+                if self.interrupt:
+                    continue
+                if fused:
+                    # concat(sdr, gm) + CFG duplicate + cast fused into the input pack; CFG/rescale/PLMS in one kernel
+                    x = self.unet.pack_input((sdr_f32, latents), dup=2 if do_cfg else 1)
+                    self.unet.set_timestep(t)
+                    hw = latents.shape[-2:]
+                    noise_pred = self.unet.forward_packed(x, x.shape[0], hw[0], hw[1], ctx)
+                    latents, _ = self.scheduler.fused_step(noise_pred, t, latents, do_cfg, self.guidance_scale,
+                                                           self.guidance_rescale if do_cfg else 0.0)
+                else:
+                    cat_latents = torch.cat([sdr_latent, latents], dim=1)
+                    latent_model_input = torch.cat([cat_latents] * 2) if do_cfg else cat_latents
+                    latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+                    noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, timestep_cond=None,
+                                           cross_attention_kwargs=self.cross_attention_kwargs, added_cond_kwargs=None,
+                                           return_dict=False)[0]
+                    if do_cfg:
+                        noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+                        noise_pred = noise_pred_uncond + self.guidance_scale * (noise_pred_text - noise_pred_uncond)
+                    if do_cfg and self.guidance_rescale > 0.0:
+                        noise_pred = rescale_noise_cfg(noise_pred, noise_pred_text, guidance_rescale=self.guidance_rescale)
+                    latents = self.scheduler.step(noise_pred, t, latents, **extra_step_kwargs, return_dict=False)[0]
+
+                if callback_on_step_end is not None:
+                    callback_kwargs = {}
+                    for k in callback_on_step_end_tensor_inputs:
+                        callback_kwargs[k] = locals()[k]
+                    callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
+                    latents = callback_outputs.pop("latents", latents)
+                    new_pe = callback_outputs.pop("prompt_embeds", prompt_embeds)
+                    if new_pe is not prompt_embeds:
+                        prompt_embeds = new_pe
+                        if fused:
+                            ctx = self.unet.prepare_context(prompt_embeds)
+                    negative_prompt_embeds = callback_outputs.pop("negative_prompt_embeds", negative_prompt_embeds)
+
+                if i == len(timesteps) - 1 or ((i + 1) > num_warmup_steps and (i + 1) % self.scheduler.order == 0):
+                    progress_bar.update()
+                    if callback is not None and i % callback_steps == 0:
+                        step_idx = i // getattr(self.scheduler, "order", 1)
+                        callback(step_idx, t, latents)
+
+        if not output_type == "latent":
+            image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False, generator=generator)[0]
+            image, has_nsfw_concept = self.run_safety_checker(image, device, prompt_embeds.dtype)
+        else:
+            image = latents
+            has_nsfw_concept = None
+        if has_nsfw_concept is None:
+            do_denormalize = [True] * image.shape[0]
+        else:
+            do_denormalize = [not has_nsfw for has_nsfw in has_nsfw_concept]
+        image = self.image_processor.postprocess(image, output_type=output_type, do_denormalize=do_denormalize)
+        self.maybe_free_model_hooks()
+        if not return_dict:
+            return (image, has_nsfw_concept)
+        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=has_nsfw_concept)

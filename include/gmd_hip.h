@@ -1,0 +1,204 @@
+/*
+ * gmd_hip.h -- C ABI of libgmd_hip.so: the MI355X (gfx950 / CDNA4) kernels behind
+ * GM-Diffusion's Stage-3 hot path (SDR+GM denoising loop, VAE decode, gain-map HDR
+ * recomposition).
+ *
+ * The reference (Guanys-dar/GM-Diffusion) is pure Python with NO FFI / plugin / C
+ * interface: the heavy arithmetic is whatever torch/cuDNN/diffusers
+ * dispatch.  This ABI is therefore new; each entry point cites the reference
+ * expression (file:line, relative to the reference root) whose arithmetic it
+ * replaces.  The Python host side (gm-diffusion_amd/gm_diffusion) binds it with
+ * ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named *_host; no allocation inside;
+ *     the caller owns all buffers (workspace sizes documented per call);
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*) and
+ *     never synchronises, so calls are hipGraph-capturable;
+ *   - return value: GMD_OK or an error code; gmd_last_error() returns a thread-local
+ *     message for the last failing call;
+ *   - activations are channels-last: [B, H*W, C] ("NHWC"); `dtype` selects the
+ *     activation/weight element type (GMD_BF16 = MFMA path, GMD_F32 = parity path);
+ *     biases, norm affine parameters and statistics are always float32.
+ */
+#ifndef GMD_HIP_H
+#define GMD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMD_ABI_VERSION 1
+
+#define GMD_OK 0
+#define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
+#define GMD_ERR_LAUNCH 2      /* hipLaunch / runtime failure */
+#define GMD_ERR_UNSUPPORTED 3 /* valid request this build does not implement */
+
+#define GMD_F32 0
+#define GMD_BF16 1
+
+/* epilogue activation for gmd_gemm_nt */
+#define GMD_ACT_NONE 0
+#define GMD_ACT_SILU 1
+
+typedef void* gmd_stream_t;
+
+int gmd_abi_version(void);
+const char* gmd_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * HDR tail
+ * ---------------------------------------------------------------------------------- */
+
+/* Fused Stage-3 tail, one pass over the two decoded images:
+ *   sdr = clamp(sdr_dec/2+0.5, 0, 1), gm likewise      scripts/inference/generate_hdr.py:227-228,232-233
+ *   u8  = (x*255) truncated                             generate_hdr.py:244-245
+ *   hdr = (sdr^2.2 + eps)*(1 + gm*qmax) - eps           gm_diffusion/stage1/tone_mapping.py:68-70,
+ *                                                       scripts/inference/experiments/formal_improved.py:34-45
+ *   [clamp(hdr, 0, qmax+1) when flags&1]                tone_mapping.py:71
+ *   hdr_file = hdr/(qmax+1)                             generate_hdr.py:27-29
+ *   hdr_u16  = rint(clamp(hdr_file*65535, 0, 65535))    gm_diffusion/stage1/augmentations.py:38-41
+ * Inputs: decoder outputs [B,3,H,W] (in_layout 0) or [B,H,W,3] (in_layout 1), in_dtype F32/BF16.
+ * Outputs are [B,H,W,3]; any output pointer may be NULL. */
+int gmd_hdr_tail(const void* sdr_dec, const void* gm_dec, int in_dtype, int in_layout,
+                 int B, int H, int W, float qmax, float eps, int flags,
+                 float* sdr_img, float* gm_img, uint8_t* sdr_u8, uint8_t* gm_u8,
+                 float* hdr, float* hdr_file, uint16_t* hdr_u16, gmd_stream_t stream);
+
+/* tone_mapping.py:60-71 apply_gm_to_sdr (clamp!=0) / formal_improved.py:34-45 (clamp==0); any shape, n elements */
+int gmd_apply_gm_to_sdr(const float* gm, const float* sdr, float* out, int64_t n,
+                        float qmax, float eps, int clamp, gmd_stream_t stream);
+/* kind 0: linear_scale_tmo tone_mapping.py:14-18; 1: hard_clip_tmo :21-26;
+ * 2: mu-log (fix_mulog_tmo :29-36 with mu=500, random_tmo_cuda :50-57 with the drawn mu);
+ * 3: tmo_cuda :39-47 (mu=5000, /10 pre-scale);
+ * 4: decode post-process clamp(x/2+0.5, 0, 1), gm_diffusion/pipelines/stable_diffusion_gm.py:606;
+ * 5: x*mu (1/scaling_factor*latents, generate_hdr.py:225); 6: x/mu (latents/scaling_factor, stable_diffusion_gm.py:1094) */
+int gmd_tmo(const float* in, float* out, int64_t n, int kind, float qmax, float mu, gmd_stream_t stream);
+/* tone_mapping.py:74-90 gamut_compress on [B,3,HW] planar input */
+int gmd_gamut_compress(const float* in, float* out, int B, int64_t HW, gmd_stream_t stream);
+/* scripts/stage1/train_vqgan_lora.py:1133-1141: apply_gm_to_sdr(clamped) -> fix_mulog_tmo -> gamut_compress, planar [B,3,HW] */
+int gmd_stage1_chain(const float* gm, const float* sdr, float* out, int B, int64_t HW, float qmax, gmd_stream_t stream);
+/* augmentations.py:38-41 discretize_to_uint16; out_float and/or out_codes may be NULL */
+int gmd_discretize_u16(const float* in, float* out_float, uint16_t* out_codes, int64_t n, gmd_stream_t stream);
+/* generate_hdr.py:244-245 (x*255).astype(uint8) */
+int gmd_quantize_u8(const float* in, uint8_t* out, int64_t n, gmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * latent-side fused step
+ * ---------------------------------------------------------------------------------- */
+
+/* One pass over a [B,4,h,w] fp32 latent: classifier-free-guidance combine
+ * (stable_diffusion_dual_unet.py:1063-1065), optional per-sample guidance rescale factor
+ * (:1067-1069, rescale_noise_cfg :71-94; `rescale_ratio` = std_text/std_cfg per sample from
+ * gmd_cfg_std_ratio), x0 prediction (:1071-1075) and the PNDM/PLMS linear-multistep update
+ * (diffusers PNDMScheduler.step_plms/_get_prev_sample, called at :1077 and :1093).
+ *   mode 0: eps' = eps                        (first step)
+ *   mode 1: eps' = (eps + e1)/2, sample = cur_sample   (PLMS counter==1 redo step)
+ *   mode 2: eps' = (3 eps - e1)/2
+ *   mode 3: eps' = (23 eps - 16 e1 + 5 e2)/12
+ *   mode 4: eps' = (55 eps - 59 e1 + 37 e2 - 9 e3)/24
+ *   x_prev = sample_coeff*sample - (alpha_delta*eps')/denom
+ * eps_in: [2B,4,h,w] (uncond half first) when do_cfg else [B,4,h,w].
+ * eps_out (the guided eps, appended to the scheduler history by the host), x_prev, x0 may alias nothing.
+ * Arithmetic is float32 without FMA contraction, in torch's operation order: results are
+ * bit-identical to the CPU reference given identical eps. */
+int gmd_latent_step(const float* eps_in, const float* x, const float* cur_sample,
+                    const float* e1, const float* e2, const float* e3,
+                    int B, int64_t chw, int do_cfg, float guidance_scale,
+                    const float* rescale_ratio, float guidance_rescale,
+                    int mode, float sample_coeff, float alpha_delta, float denom,
+                    float sqrt_alpha, float sqrt_one_minus_alpha,
+                    float* eps_out, float* x_prev, float* x0, gmd_stream_t stream);
+
+/* per-sample unbiased std of the text eps and of the guided eps -> ratio[b] = std_text/std_cfg
+ * (rescale_noise_cfg, stable_diffusion_dual_unet.py:88-91) */
+int gmd_cfg_std_ratio(const float* eps_in, int B, int64_t chw, float guidance_scale,
+                      float* ratio, gmd_stream_t stream);
+
+/* 8-channel concat + CFG duplicate + NCHW->NHWC + cast + zero channel padding in one pass
+ * (stable_diffusion_gm.py:1045-1047 cat([sdr_latent, latents],1) then cat([.]*2);
+ *  stable_diffusion_dual_unet.py:1045, 1080).  src0 [B,C0,HW] f32, src1 [B,C1,HW] f32 or NULL;
+ * out [dup*B, HW, CP] of out_dtype with channels >= C0+C1 zeroed. */
+int gmd_pack_unet_input(const float* src0, int C0, const float* src1, int C1, int B, int64_t HW,
+                        int dup, void* out, int CP, int out_dtype, gmd_stream_t stream);
+/* [B,HW,ld] (first C channels) of in_dtype -> [B,C,HW] float32 */
+int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int64_t HW,
+                    float* out, gmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * UNet / VAE building blocks (arithmetic lives in the un-vendored
+ * `diffusers` dependency: UNet2DConditionModel / AutoencoderKL called at
+ * stable_diffusion_gm.py:1051,1094 and stable_diffusion_dual_unet.py:1052,1083)
+ * ---------------------------------------------------------------------------------- */
+
+/* C[b] = act(alpha * A[b] @ W[b]^T + bias + rowbias + residual).
+ * A: [M,K] ld lda; W: [N,K] ld ldw (both K-contiguous); C: [M,N] ld ldc, out_dtype F32 or `dtype`.
+ * bias: float32 [N] or NULL.  rowbias: float32 [ceil(M/rows_per_group), N] or NULL, added to rows
+ * of group m/rows_per_group (ResnetBlock2D time-embedding add).  residual: `dtype` [M,N] ld ldr or NULL.
+ * Requirements: K % 64 == 0 (BF16) / K % 4 == 0 (F32); lda, ldw multiples of 8 (BF16) / 4 (F32) elements;
+ * base pointers 16-byte aligned.  nn.Linear / conv1x1 / attention score products. */
+int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
+                int M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
+                int batch, int64_t strideA, int64_t strideW, int64_t strideC,
+                const float* bias, const float* rowbias, int rows_per_group,
+                const void* residual, int64_t ldr, int64_t strideR,
+                float alpha, int act, gmd_stream_t stream);
+
+/* 3x3 convolution, padding 1, as an implicit GEMM over channels-last data.
+ * X: [B,Hin,Win,Cin]; Wt: [Cout, 9*Cin] with k = (ky*3+kx)*Cin + c; Y: [B,Hout,Wout,Cout].
+ * stride 1 or 2 (Downsample2D: Hout = (Hin+2-3)/2+1); upsample=1 fuses nearest-2x
+ * (Upsample2D: conv over the virtual 2Hin x 2Win image).  pad_mode 0: symmetric padding 1;
+ * pad_mode 1: pad (0,1,0,1) then stride 2 (VAE encoder Downsample2D(padding=0)).
+ * Epilogue as gmd_gemm_nt (rowbias is [B,Cout]).  Cin % 64 == 0 (BF16) / % 16 (F32). */
+int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype,
+                int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode,
+                const float* bias, const float* rowbias, const void* residual,
+                gmd_stream_t stream);
+
+/* Flash-style attention, bf16 MFMA: O = softmax(scale * Q K^T) V per (batch, head).
+ * Q: [B,Nq,*] head h at columns h*D..h*D+D, row stride ldq; K likewise (ldk);
+ * Vt: V transposed, [B, H*D, ldvt] (keys contiguous, ldvt >= Nk, multiple of 8);
+ * O: [B,Nq,H*D] row stride ldo.  D in {32,40,64,80,160}. */
+int gmd_attention(const void* Q, const void* K, const void* Vt, void* O, int dtype,
+                  int B, int H, int D, int Nq, int Nk,
+                  int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
+                  int64_t strideQ, int64_t strideK, int64_t strideVt, int64_t strideO,
+                  float scale, gmd_stream_t stream);
+
+/* row softmax: P[r, :cols] = softmax(scale * S[r, :cols]); S float32 ld lds, P out_dtype ld ldp;
+ * columns cols..ldp-1 of P are zero-filled. */
+int gmd_softmax_rows(const float* S, int64_t lds, void* P, int out_dtype, int64_t ldp,
+                     int64_t rows, int cols, float scale, gmd_stream_t stream);
+
+/* GroupNorm statistics over channels-last X [B,HW,C] -> per (b,c) affine
+ * scale_shift[b][c] = {rstd*gamma[c], beta[c]-mean*rstd*gamma[c]}.
+ * workspace: float32, at least B*nsplit*G*2 floats where nsplit = gmd_groupnorm_nsplit(HW). */
+int gmd_groupnorm_nsplit(int64_t HW);
+int gmd_groupnorm_stats(const void* X, int dtype, int B, int64_t HW, int C, int G, float eps,
+                        const float* gamma, const float* beta, float* workspace,
+                        float* scale_shift, gmd_stream_t stream);
+/* Y = [silu](X*scale+shift) */
+int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, int C,
+                        const float* scale_shift, int silu, gmd_stream_t stream);
+/* LayerNorm over the last dim (C % 8 == 0, C <= 2048) */
+int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C,
+                  const float* gamma, const float* beta, float eps, gmd_stream_t stream);
+/* GEGLU: Y[r, f] = X[r, f] * gelu_erf(X[r, F + f]); X [rows, 2F], Y [rows, F] */
+int gmd_geglu(const void* X, void* Y, int dtype, int64_t rows, int F, gmd_stream_t stream);
+/* sinusoidal timestep embedding (diffusers get_timestep_embedding): out [B, dim] of `dtype`;
+ * timestep read from DEVICE memory (t_dev, float32 scalar) so captured graphs can be replayed. */
+int gmd_timestep_embedding(const float* t_dev, void* out, int dtype, int B, int dim,
+                           int flip_sin_to_cos, float freq_shift, gmd_stream_t stream);
+/* out[r, :Ca] = A[r], out[r, Ca:] = Bm[r]  (skip-connection concat, channels-last) */
+int gmd_concat_channels(const void* A, int Ca, const void* Bm, int Cb, void* out, int dtype,
+                        int64_t rows, gmd_stream_t stream);
+/* elementwise cast between F32 and BF16 */
+int gmd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, gmd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMD_HIP_H */

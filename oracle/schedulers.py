@@ -31,7 +31,11 @@ def _betas(cfg):
 class _Config(dict):
     """dict with attribute access (diffusers FrozenDict behaviour the pipelines rely on)."""
 
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 class PNDMScheduler:

@@ -1,0 +1,425 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI via gm_diffusion.hip_ops)
+against plain PyTorch fp32/fp64 references and the oracle's golden vectors."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from gm_diffusion import hip_ops
+
+    return hip_ops
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_err(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.5e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# HDR tail
+# ---------------------------------------------------------------------------------------------
+def test_hdr_ops_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hdr_ops_reference.npz"))
+    o = ops()
+    sdr, gm = torch.from_numpy(g["sdr"]).to(DEV), torch.from_numpy(g["gm"]).to(DEV)
+    for q in (9, 49, 99):
+        ref = torch.from_numpy(g[f"apply_gm_to_sdr_q{q}"])
+        got = o.apply_gm_to_sdr(gm, sdr, qmax=q)
+        assert rel_err(got, ref) < 2e-7 and max_err(got, ref) <= 4e-6 * (q + 1)
+        hdr = ref.to(DEV)
+        assert max_err(o.tmo(hdr, 2, qmax=q, mu=500.0), torch.from_numpy(g[f"fix_mulog_tmo_q{q}"])) <= 2.4e-7
+        assert torch.equal(o.tmo(hdr, 0, qmax=q).cpu(), torch.from_numpy(g[f"linear_scale_tmo_q{q}"]))
+        assert torch.equal(o.tmo(hdr, 1).cpu(), torch.from_numpy(g[f"hard_clip_tmo_q{q}"]))
+        assert max_err(o.stage1_chain(gm, sdr, q), torch.from_numpy(g[f"stage1_chain_q{q}"])) <= 1e-6
+    assert max_err(o.tmo(torch.from_numpy(g["apply_gm_to_sdr_q9"]).to(DEV), 3), torch.from_numpy(g["tmo_cuda"])) <= 2.4e-7
+    assert max_err(o.gamut_compress(sdr), torch.from_numpy(g["gamut_compress"])) <= 2.4e-7
+    mu = float(g["random_tmo_mu"])
+    assert max_err(o.tmo(torch.from_numpy(g["apply_gm_to_sdr_q49"]).to(DEV), 2, qmax=49, mu=mu),
+                   torch.from_numpy(g["random_tmo_cuda_q49"])) <= 2.4e-7
+    # integer / exactly-rounded ops: bit exact
+    u16 = o.discretize_u16(torch.from_numpy(g["u16_in"]).to(DEV))
+    assert torch.equal(u16.cpu(), torch.from_numpy(g["discretize_to_uint16"]))
+    # denorm: exact
+    assert torch.equal(o.tmo(torch.from_numpy(g["sdr_dec"]).to(DEV), 4).cpu(), torch.from_numpy(g["sdr"]))
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hdr_tail_fused_vs_oracle(layout, dtype):
+    from oracle import hdr_ops as H
+
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    B, Hh, W = 2, 20, 36
+    sdr_dec = (torch.rand(B, 3, Hh, W, generator=g) * 2.4 - 1.2).to(dtype)
+    gm_dec = (torch.rand(B, 3, Hh, W, generator=g) * 2.4 - 1.2).to(dtype)
+    ref = H.hdr_tail(sdr_dec.float().numpy(), gm_dec.float().numpy(), qmax=99, clamp=False)
+
+    def lay(x):
+        if layout == 0:
+            return x.contiguous()
+        n = x.permute(0, 2, 3, 1)
+        if layout == 2:
+            n = torch.cat([n, torch.full_like(n[..., :1], 7.0)], -1)
+        return n.reshape(B, Hh * W, -1).contiguous()
+
+    out = o.hdr_tail(lay(sdr_dec).to(DEV), lay(gm_dec).to(DEV), layout, B, Hh, W, qmax=99.0, clamp=False)
+    assert torch.equal(out["sdr"].cpu(), torch.from_numpy(ref["sdr"]))
+    assert torch.equal(out["gm"].cpu(), torch.from_numpy(ref["gm"]))
+    assert torch.equal(out["sdr_u8"].cpu(), torch.from_numpy(ref["sdr_u8"]))  # integer: bit exact
+    assert torch.equal(out["gm_u8"].cpu(), torch.from_numpy(ref["gm_u8"]))
+    assert rel_err(out["hdr"], torch.from_numpy(ref["hdr"])) < 2e-7
+    assert rel_err(out["hdr_file"], torch.from_numpy(ref["hdr_file"])) < 2e-7
+    # the u16 quantiser is exact given ITS float input: check against the kernel's own hdr_file
+    codes = H.quantize_u16_codes(out["hdr_file"].cpu().numpy())
+    assert np.array_equal(out["hdr_u16"].cpu().numpy(), codes)
+    # and report (not gate) the end-to-end mismatch caused by <=1ulp powf differences
+    mism = (out["hdr_u16"].cpu().numpy() != H.quantize_u16_codes(ref["hdr_file"])).mean()
+    assert mism < 0.02
+    # clamped variant (torch apply_gm_to_sdr)
+    out_c = o.hdr_tail(lay(sdr_dec).to(DEV), lay(gm_dec).to(DEV), layout, B, Hh, W, qmax=9.0, clamp=True, want=("hdr",))
+    ref_c = H.apply_gm_to_sdr(ref["gm"], ref["sdr"], qmax=9, clamp=True)
+    assert rel_err(out_c["hdr"], torch.from_numpy(ref_c)) < 2e-7
+
+
+def test_quantisers_bit_exact_large():
+    o = ops()
+    from oracle import hdr_ops as H
+
+    x = torch.rand(1 << 20, generator=torch.Generator().manual_seed(5)) * 1.1 - 0.05
+    assert np.array_equal(o.discretize_u16(x.to(DEV), codes=True)[1].cpu().numpy(), H.quantize_u16_codes(x.numpy()))
+    x01 = x.clamp(0, 1)
+    assert np.array_equal(o.quantize_u8(x01.to(DEV)).cpu().numpy(), H.quantize_u8_trunc(x01.numpy()))
+    # idempotence of the discretiser
+    d1 = o.discretize_u16(x.to(DEV))
+    assert torch.equal(o.discretize_u16(d1), d1)
+
+
+def test_hdr_empty_inputs():
+    o = ops()
+    e = torch.empty(0, dtype=torch.float32, device=DEV)
+    assert o.tmo(e, 1).numel() == 0 and o.discretize_u16(e).numel() == 0 and o.quantize_u8(e).numel() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# latent step / pack / unpack
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("do_cfg", [False, True])
+def test_latent_step_bit_exact_vs_torch_pndm(do_cfg):
+    """Drive the product PNDM scheduler on device tensors and the oracle PNDM on CPU tensors with
+    identical eps; every step must agree bit for bit."""
+    from gm_diffusion.components import PNDMScheduler
+    from oracle import schedulers as OS
+
+    B, shape = 3, (3, 4, 8, 8)
+    g = torch.Generator().manual_seed(11)
+    sp = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1)
+    so = OS.PNDMScheduler()
+    sp.set_timesteps(10)
+    so.set_timesteps(10)
+    assert torch.equal(sp.timesteps, so.timesteps)
+    x_cpu = torch.randn(shape, generator=g)
+    x_dev = x_cpu.to(DEV)
+    gs = 7.5
+    for t in so.timesteps:
+        raw = torch.randn((2 * B if do_cfg else B,) + shape[1:], generator=g)
+        if do_cfg:
+            u, c = raw.chunk(2)
+            eps = u + gs * (c - u)
+        else:
+            eps = raw
+        a = so.alphas_cumprod[t].view(-1, 1, 1, 1)
+        x0_ref = (x_cpu - (1 - a).sqrt() * eps) / a.sqrt()
+        x_cpu = so.step(eps, t, x_cpu, return_dict=False)[0]
+        x_dev, x0 = sp.fused_step(raw.to(DEV), t, x_dev, do_cfg, gs, want_x0=True)
+        assert torch.equal(x0.cpu(), x0_ref), f"x0 differs at t={int(t)}"
+        assert torch.equal(x_dev.cpu(), x_cpu), f"x_prev differs at t={int(t)}"
+
+
+def test_pndm_step_protocol_device_equals_host():
+    from gm_diffusion.components import PNDMScheduler
+
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1)
+    sd, sh = PNDMScheduler(**kw), PNDMScheduler(**kw)
+    sd.set_timesteps(7)
+    sh.set_timesteps(7)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    xd = x.to(DEV)
+    for t in sh.timesteps:
+        e = torch.randn(2, 4, 8, 8, generator=g)
+        x = sh.step(e, t, x, return_dict=False)[0]
+        xd = sd.step(e.to(DEV), t, xd, return_dict=False)[0]
+        assert torch.equal(xd.cpu(), x)
+
+
+def test_cfg_rescale_matches_torch():
+    from oracle import pipelines as OP
+
+    o = ops()
+    g = torch.Generator().manual_seed(4)
+    raw = torch.randn(6, 4, 16, 16, generator=g)
+    u, c = raw.chunk(2)
+    cfg = u + 5.0 * (c - u)
+    ref = OP.rescale_noise_cfg(cfg, c, 0.7)
+    ratio = o.cfg_std_ratio(raw.to(DEV), 5.0)
+    x = torch.randn(3, 4, 16, 16, generator=g)
+    eps, _, _ = o.latent_step(raw.to(DEV), x.to(DEV), 0, (1.0, 0.1, 1.0, 1.0, 0.0), True, 5.0, ratio=ratio, guidance_rescale=0.7)
+    assert rel_err(eps, ref) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_unpack(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(2, 4, 6, 10, generator=g), torch.randn(2, 4, 6, 10, generator=g)
+    cp = 64 if dtype == torch.bfloat16 else 16
+    out = o.pack_unet_input(a.to(DEV), b.to(DEV), 2, cp, dtype).cpu().float()
+    ref = torch.cat([a, b], 1).permute(0, 2, 3, 1).reshape(2, 60, 8).to(dtype).float()
+    assert out.shape == (4, 60, cp)
+    assert torch.equal(out[:2, :, :8], ref) and torch.equal(out[2:, :, :8], ref)
+    assert float(out[:, :, 8:].abs().max()) == 0.0
+    single = o.pack_unet_input(a.to(DEV), None, 1, cp, dtype)
+    back = o.unpack_nchw(single, 2, 4, 6, 10).cpu()
+    assert torch.equal(back, a.to(dtype).float())
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation / elementwise
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,HW,C,G", [(2, 64, 320, 32), (1, 4096, 320, 32), (2, 256, 1280, 32), (1, 64, 2560, 32),
+                                      (2, 100, 128, 32), (1, 16, 960, 32), (3, 37, 64, 8)])
+def test_groupnorm(dtype, B, HW, C, G):
+    o = ops()
+    g = torch.Generator().manual_seed(C + HW)
+    x = (torch.randn(B, HW, C, generator=g) * 2 + 0.5).to(dtype)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xn = x.float().permute(0, 2, 1).reshape(B, C, HW, 1)
+    for silu in (False, True):
+        ref = F.group_norm(xn, G, gamma, beta, 1e-5)
+        ref = F.silu(ref) if silu else ref
+        ref = ref.reshape(B, C, HW).permute(0, 2, 1)
+        got = o.groupnorm(x.to(DEV), B, G, gamma.to(DEV), beta.to(DEV), 1e-5, silu=silu)
+        assert rel_err(got.float(), ref) < (2e-6 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(5, 320), (130, 640), (64, 1280), (3, 64), (9, 2048)])
+def test_layernorm(dtype, rows, C):
+    o = ops()
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, C, generator=g) * 3 - 1).to(dtype)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    got = o.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5)
+    assert rel_err(got.float(), ref) < (2e-6 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_geglu_concat_cast_temb_softmax(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(37, 2 * 1280, generator=g).to(dtype)
+    h, gate = x.float().chunk(2, -1)
+    assert rel_err(o.geglu(x.to(DEV)).float(), h * F.gelu(gate)) < tol(dtype)
+    a, b = torch.randn(33, 640, generator=g).to(dtype), torch.randn(33, 320, generator=g).to(dtype)
+    assert torch.equal(o.concat_channels(a.to(DEV), b.to(DEV)).cpu(), torch.cat([a, b], -1))
+    f = torch.randn(1001, generator=g)
+    assert torch.equal(o.cast(f.to(DEV), torch.bfloat16).cpu(), f.to(torch.bfloat16))
+    # timestep embedding vs the oracle
+    from oracle.unet import timestep_embedding
+
+    for t in (981.0, 1.0, 501.0):
+        td = torch.tensor([t], device=DEV)
+        got = o.timestep_embedding(td, 3, 320, torch.float32)
+        ref = timestep_embedding(torch.full((3,), t), 320)
+        assert max_err(got, ref) < 2e-4  # |arg| up to 1e3: a few ulp of the argument
+    # row softmax
+    s = torch.randn(70, 77, generator=g) * 4
+    p = o.softmax_rows(F.pad(s, (0, 3)).contiguous().to(DEV), 77, 0.3, dtype, ldp=80)
+    assert rel_err(p[:, :77].float(), torch.softmax(s * 0.3, -1)) < tol(dtype)
+    assert float(p[:, 77:].float().abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM / conv
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 320), (8, 1280, 1280), (616, 320, 768), (4096, 320, 320),
+                                   (2048, 2560, 320), (33, 4, 128), (70, 1000, 64), (1024, 1280, 5120)])
+def test_gemm_nt(dtype, M, N, K):
+    o = ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(dtype)
+    ref = a.double() @ w.double().t()
+    got = o.gemm_nt(a.to(DEV), w.to(DEV))
+    assert rel_err(got.float(), ref) < tol(dtype), "plain"
+    got = o.gemm_nt(a.to(DEV), w.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), alpha=0.5)
+    assert rel_err(got.float(), 0.5 * ref + bias.double() + res.double()) < tol(dtype), "bias+residual"
+    got = o.gemm_nt(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=o.ACT_SILU, out_dtype=torch.float32)
+    assert got.dtype == torch.float32
+    assert rel_err(got, F.silu(ref + bias.double())) < tol(dtype), "silu f32 out"
+    rpg = 7
+    rb = torch.randn((M + rpg - 1) // rpg, N, generator=g)
+    got = o.gemm_nt(a.to(DEV), w.to(DEV), rowbias=rb.to(DEV), rows_per_group=rpg)
+    assert rel_err(got.float(), ref + rb.double().repeat_interleave(rpg, 0)[:M]) < tol(dtype), "rowbias"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_and_swapped(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(9)
+    Bn, N, C = 3, 72, 128
+    x = torch.randn(Bn, N, C, generator=g).to(dtype)
+    wv = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype)
+    ld = 80
+    vt = o.gemm_nt(wv.to(DEV), x.to(DEV), ldc=ld)  # V^T[b] = W_v @ x[b]^T
+    ref = torch.einsum("ck,bnk->bcn", wv.double(), x.double())
+    assert vt.shape == (Bn, C, ld)
+    assert rel_err(vt[:, :, :N].float(), ref) < tol(dtype)
+    y = o.gemm_nt(x.to(DEV), torch.stack([wv, wv * 2, wv * 3]).to(DEV))
+    ref2 = torch.stack([x[i].double() @ (wv.double() * (i + 1)).t() for i in range(3)])
+    assert rel_err(y.float(), ref2) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [
+    (2, 8, 8, 64, 64, "s1"), (1, 16, 12, 128, 320, "s1"), (2, 8, 8, 64, 128, "s2"), (1, 9, 7, 64, 64, "s2"),
+    (2, 4, 6, 128, 64, "up"), (1, 8, 8, 64, 64, "pad1"), (1, 7, 9, 64, 64, "pad1"), (1, 64, 64, 320, 320, "s1"),
+    (2, 8, 8, 64, 4, "s1"), (8, 8, 8, 1280, 1280, "s1"),
+])
+def test_conv3x3(dtype, B, H, W, Cin, Cout, mode):
+    o = ops()
+    g = torch.Generator().manual_seed(H * W + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
+    bias = torch.randn(Cout, generator=g)
+    xd, wd = x.double(), w.double()
+    if mode == "s1":
+        ref = F.conv2d(xd, wd, bias.double(), padding=1)
+        kw = {}
+    elif mode == "s2":
+        ref = F.conv2d(xd, wd, bias.double(), stride=2, padding=1)
+        kw = dict(stride=2)
+    elif mode == "up":
+        ref = F.conv2d(F.interpolate(xd, scale_factor=2.0, mode="nearest"), wd, bias.double(), padding=1)
+        kw = dict(upsample=True)
+    else:
+        ref = F.conv2d(F.pad(xd, (0, 1, 0, 1)), wd, bias.double(), stride=2, padding=0)
+        kw = dict(stride=2, pad_mode=1)
+    Ho, Wo = ref.shape[-2:]
+    xl = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous().to(DEV)
+    wl = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(DEV)
+    tb = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Ho * Wo, Cout, generator=g).to(dtype)
+    y, ho, wo = o.conv3x3(xl, wl, B, H, W, bias=bias.to(DEV), rowbias=tb.to(DEV), residual=res.to(DEV), **kw)
+    assert (ho, wo) == (Ho, Wo)
+    full = ref + tb.double()[:, :, None, None]
+    full = full.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout) + res.double()
+    assert rel_err(y.float(), full) < tol(dtype)
+    y32, _, _ = o.conv3x3(xl, wl, B, H, W, bias=bias.to(DEV), out_dtype=torch.float32, **kw)
+    assert y32.dtype == torch.float32
+    assert rel_err(y32, ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)) < tol(dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, heads, scale):
+    B, Nq, C = q.shape
+    d = C // heads
+    qh = q.double().view(B, Nq, heads, d).transpose(1, 2)
+    kh = k.double().view(B, -1, heads, d).transpose(1, 2)
+    vh = v.double().view(B, -1, heads, d).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("D", [32, 40, 64, 80, 160])
+@pytest.mark.parametrize("Nq,Nk", [(256, 256), (64, 77), (16, 16), (200, 130), (1024, 1024)])
+def test_attention_bf16(D, Nq, Nk):
+    o = ops()
+    heads, B = 2, 2
+    C = heads * D
+    g = torch.Generator().manual_seed(D * 7 + Nq + Nk)
+    q = torch.randn(B, Nq, C, generator=g).bfloat16()
+    k = torch.randn(B, Nk, C, generator=g).bfloat16()
+    v = torch.randn(B, Nk, C, generator=g).bfloat16()
+    ld = (Nk + 7) // 8 * 8
+    vt = torch.full((B, C, ld), float("nan")).bfloat16()  # pad columns poisoned: the kernel must mask them
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    scale = D ** -0.5
+    got = o.attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads, Nk, scale)
+    ref = _attn_ref(q, k, v, heads, scale)
+    assert torch.isfinite(got.float()).all()
+    assert rel_err(got.float(), ref) < 1.2e-2
+    assert max_err(got.float(), ref) < 6e-2
+
+
+def test_attention_rescale_branch_spiked_keys():
+    """Force the running max to jump in a later tile (rare online-softmax branch)."""
+    o = ops()
+    heads, B, D, N = 1, 1, 40, 320
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B, N, D, generator=g)
+    k = torch.randn(B, N, D, generator=g) * 0.3
+    v = torch.randn(B, N, D, generator=g)
+    k[0, 200] = q[0, 5] * 3.0   # query 5 sees a huge score at key 200 (4th tile)
+    k[0, 310] = q[0, 100] * 4.0
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    vt = v.transpose(1, 2).contiguous()
+    got = o.attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads, N, D ** -0.5)
+    ref = _attn_ref(q, k, v, heads, D ** -0.5)
+    assert max_err(got.float(), ref) < 6e-2 and rel_err(got.float(), ref) < 1.2e-2
+
+
+def test_attention_fused_qk_buffer():
+    o = ops()
+    heads, B, D, N = 8, 2, 40, 256
+    C = heads * D
+    g = torch.Generator().manual_seed(5)
+    qk = torch.randn(B, N, 2 * C, generator=g).bfloat16()
+    v = torch.randn(B, N, C, generator=g).bfloat16()
+    got = o.attention(qk.to(DEV), qk.to(DEV), v.transpose(1, 2).contiguous().to(DEV), heads, N, D ** -0.5, k_col=C)
+    ref = _attn_ref(qk[..., :C], qk[..., C:], v, heads, D ** -0.5)
+    assert rel_err(got.float(), ref) < 1.2e-2
+
+
+@pytest.mark.parametrize("dtype,d,heads", [(torch.float32, 40, 8), (torch.float32, 32, 2), (torch.bfloat16, 512, 1)])
+def test_composed_attention(dtype, d, heads):
+    from gm_diffusion.components.unet_2d_condition import composed_attention
+
+    B, Nq, Nk = 2, 128, 77 if dtype == torch.float32 else 128
+    C = heads * d
+    g = torch.Generator().manual_seed(d)
+    q = torch.randn(B, Nq, C, generator=g).to(dtype)
+    k = torch.randn(B, Nk, C, generator=g).to(dtype)
+    v = torch.randn(B, Nk, C, generator=g).to(dtype)
+    mul = 64 if dtype == torch.bfloat16 else 4
+    ld = (Nk + mul - 1) // mul * mul
+    vt = torch.zeros(B, C, ld, dtype=dtype)
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    got = composed_attention(q.to(DEV), 0, C, k.to(DEV), 0, C, vt.to(DEV), B, heads, d, Nq, Nk, d ** -0.5, dtype)
+    ref = _attn_ref(q, k, v, heads, d ** -0.5)
+    assert rel_err(got.float(), ref) < (2e-5 if dtype == torch.float32 else 1.5e-2)
