@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""
+bench.py -- HDR images/sec of the Stage-3 hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic prompts:
+  dual-UNet denoising loop (50 PNDM steps -> 51 iterations; SDR UNet on 2B samples with CFG +
+  GM UNet on B samples per iteration, fused HIP latent step) -> 2 VAE decodes -> fused HDR tail
+  (Eq. 1, u8/u16 quantisation).  Text encoding is excluded (embeddings are inputs), weights are
+  synthetic (no checkpoint exists offline) -- BASELINE.md §2/§3.
+
+N=1 workload = BASELINE.json configs[1]: SD-v1-5 dual-UNet, 512x512, 50 PNDM steps, bf16, batch 4.
+N>1 (launched by torch.distributed.run, one rank per GPU over RCCL): weak scaling, batch 4 per rank;
+rank 0 builds the full-batch embeddings/latents, broadcasts them, every rank denoises its slice.
+
+Prints ONE JSON line on rank 0 (contract in the task description), with
+  "roofline":     dominant kernel, algorithmic FLOPs / HIP-event-measured time in the timed region,
+  "cpu_baseline": the CPU oracle (a port, NOT diffusers) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "gm-diffusion_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="prompts per GPU")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--unet", default="sd15", choices=["sd15", "tiny"], help="tiny = structural smoke config (not a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(res, steps, cores_hint=None):
+    """Time the CPU oracle on a bounded sample: ONE SD-1.5 UNet evaluation (batch 1) and ONE VAE decode at the bench
+    resolution, float32, all host cores; extrapolate to one HDR image = (steps+1) x (2 UNet-4ch + 1 UNet-8ch) + 2 decodes
+    (the 8-channel UNet differs only in conv_in: timed as the 4-channel one)."""
+    from oracle import fixtures
+
+    cores = cores_hint or os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    h = res // 8
+    with torch.no_grad():
+        unet = fixtures.build_unet("sd15", 4)
+        x = torch.randn(1, 4, h, h)
+        ctx = torch.randn(1, 77, 768)
+        t0 = time.perf_counter()
+        unet(x, torch.tensor(501), encoder_hidden_states=ctx)
+        t_unet = time.perf_counter() - t0
+        del unet
+        vae = fixtures.build_vae("sd15")
+        t0 = time.perf_counter()
+        vae.decode(torch.randn(1, 4, h, h))
+        t_vae = time.perf_counter() - t0
+    per_image = (steps + 1) * 3 * t_unet + 2 * t_vae
+    return {
+        "value": 1.0 / per_image, "unit": "HDR images/s", "cores": cores, "kind": "port",
+        "sample": f"CPU oracle (pure-torch fp32 restatement, NOT diffusers): 1 SD-1.5 UNet eval (batch 1, {h}x{h} latent) = "
+                  f"{t_unet:.2f}s + 1 VAE decode {res}x{res} = {t_vae:.2f}s; extrapolated to {(steps + 1) * 3} UNet evals + 2 decodes per image",
+    }
+
+
+def main():
+    a = parse()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(a.res, a.inference_steps)))
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path is hand-written HIP with no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from gm_diffusion import distributed as gdist, hdr, profiling
+    from gm_diffusion.components import AutoencoderKL, PNDMScheduler, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    tiny = a.unet == "tiny"
+    ucfg = dict(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, attention_head_dim=2, norm_num_groups=8) if tiny else {}
+    vcfg = dict(block_out_channels=(64, 64, 128, 128), norm_num_groups=8) if tiny else {}
+    t_build = time.perf_counter()
+    unet = UNet2DConditionModel(in_channels=4, **ucfg).init_random(1234).to(dev, dtype)
+    gm_unet = UNet2DConditionModel(in_channels=8, **ucfg).init_random(1238).to(dev, dtype)
+    vae = AutoencoderKL(**vcfg).init_random(1334).to(dev, dtype)
+    sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+                          skip_prk_steps=True, steps_offset=1, set_alpha_to_one=False)
+    pipe = StableDiffusionDualUNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, gm_unet=gm_unet,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+
+    B = a.batch
+    total = B * world
+    cross = unet.config.cross_attention_dim
+    h = a.res // 8
+    pos = neg = lat = None
+    if rank == 0:  # rank 0 stands in for the text encoder: full-batch hidden states + full-batch noise
+        ge = torch.Generator("cpu").manual_seed(1)
+        pos = torch.randn(total, 77, cross, generator=ge)
+        neg = torch.randn(total, 77, cross, generator=ge)
+        lat = torch.randn(total, 4, h, h, generator=torch.Generator("cpu").manual_seed(42))
+    pos, neg, lat, _ = gdist.shard_prompt_batch(pos, neg, lat, total, (77, cross), (4, h, h), torch.float32, dev)
+    pos, neg, lat = pos.to(dev), neg.to(dev), lat.to(dev)
+    unet._ensure(); gm_unet._ensure(); vae._ensure()
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    def step():
+        sdr, gm = pipe(prompt_embeds=pos, negative_prompt_embeds=neg, latents=lat, height=a.res, width=a.res,
+                       num_inference_steps=a.inference_steps, guidance_scale=7.5, output_type="latent")
+        return hdr.decode_to_hdr(vae, sdr, gm, qmax=99.0, want=("sdr_u8", "gm_u8", "hdr", "hdr_u16"))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    fence()
+    timer = None
+    if not a.no_kernel_timing and rank == 0:
+        timer = profiling.KernelTimer()
+        profiling.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    profiling.set_timer(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(out["hdr"]).all().item())
+
+    if rank == 0:
+        roof = None
+        kernels = {}
+        if timer is not None:
+            summ = timer.summary()
+            kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_us": round(v["avg_us"], 2),
+                           "tflops": round(v["tflops"], 2)} for k, v in summ.items()}
+            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            roof = {"kernel": "gmd_" + dom[0], "bound": "mfma", "achieved": round(dom[1]["tflops"], 2), "peak": BF16_DENSE_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": dom[1]["launches"], "avg_launch_us": round(dom[1]["avg_us"], 2),
+                    "share_of_kernel_time": round(dom[1]["ms"] / sum(v["ms"] for v in summ.values()), 3)}
+        res = {
+            "metric": "HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet", "value": round(total * a.steps / elapsed, 4),
+            "unit": "HDR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"SD-v1-5 dual-UNet (SDR 4ch + GM 8ch) {a.res}x{a.res}, {a.inference_steps} PNDM steps "
+                                   f"({a.inference_steps + 1} iterations), CFG 7.5, batch {B}/GPU, 2 VAE decodes + Eq.1 HDR tail"
+                                   + (" [TINY smoke config - not a valid bench]" if tiny else ""),
+                       "global_batch": total, "per_gpu_batch": B, "resolution": a.res, "inference_steps": a.inference_steps,
+                       "parallelism": f"prompt-batch sharding x{world}, RCCL broadcast of text hidden states + latents"},
+            "outputs_finite": finite, "setup_s": round(t_build, 1), "kernels": kernels, "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(a.res, a.inference_steps)
+            except Exception as e:  # pragma: no cover
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import torch
 
+from . import profiling
 from ._native import ACT_NONE, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
 
 __all__ = [
@@ -91,9 +92,14 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
         sR = M * N if residual.dim() == 3 else 0
     if bias is not None and bias.numel() != N:
         raise HipExtensionError("gemm_nt: bias must have N elements")
+    tm = profiling.active()
+    t0 = tm.begin() if tm else None
     check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, dtype_code(out_dtype), M, N, K, K, K, ldc, batch, sA, sW, sC,
                             _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")), rows_per_group,
                             _ptr(residual), N, sR, float(alpha), act, _stream()), "gmd_gemm_nt")
+    if tm:
+        es = a.element_size()
+        tm.end("gemm_nt", 2.0 * batch * M * N * K, batch * (M * K + N * K + M * N) * es, t0)
     return out
 
 
@@ -115,9 +121,14 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
         raise HipExtensionError("conv3x3: residual shape/dtype mismatch")
     if rowbias is not None and rowbias.numel() != B * cout:
         raise HipExtensionError("conv3x3: rowbias must be [B, Cout]")
+    tm = profiling.active()
+    t0 = tm.begin() if tm else None
     check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, H, W, cin, cout,
                             stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")),
                             _ptr(residual), _stream()), "gmd_conv3x3")
+    if tm:
+        tm.end("conv3x3", 2.0 * B * ho * wo * cout * 9 * cin, x.numel() * x.element_size() + w.numel() * w.element_size()
+               + y.numel() * y.element_size(), t0)
     return y, ho, wo
 
 
@@ -132,9 +143,13 @@ def attention(q, k, vt, heads, nk, scale, k_col=0):
     if k.shape[1] < nk or vt.shape[2] < nk or k_col + hd > ldk or hd > ldq:
         raise HipExtensionError("attention: operand shapes inconsistent")
     o = torch.empty((B, nq, hd), dtype=q.dtype, device=q.device)
+    tm = profiling.active()
+    t0 = tm.begin() if tm else None
     check(lib().gmd_attention(_ptr(q), _ptr(k) + k_col * k.element_size(), _ptr(vt), _ptr(o), dtype_code(q.dtype), B, heads, d,
                               nq, nk, ldq, ldk, vt.shape[2], hd, nq * ldq, k.shape[1] * ldk, hd * vt.shape[2], nq * hd,
                               float(scale), _stream()), "gmd_attention")
+    if tm:  # QK^T + PV, algorithmic head dim (padding not counted)
+        tm.end("attention", 4.0 * B * nq * nk * hd, (2 * B * nq * hd + 2 * B * nk * hd) * 2, t0)
     return o
 
 
