@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     constexpr int DC = D / 8;                 // 16-byte chunks per K row in global memory
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;                 // [KV][KROW]
-    unsigned char* Vs = smem + KV * KROW;     // [DT*32][VROW]
+    constexpr int kStageBytes = KV * KROW + DT * 32 * VROW;  // one pipeline stage: K tile [KV][KROW] + V^T tile [DT*32][VROW]
+    constexpr int NKC = (KV * DC + 255) / 256;                // 16-byte K chunks staged per thread
+    constexpr int NVC = (D * 8 + 255) / 256;                  // 16-byte V^T chunks staged per thread
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -52,13 +53,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const bf16_t* Kb = p.K + (int64_t)b * p.sK + (int64_t)head * D;
     const bf16_t* Vb = p.Vt + (int64_t)b * p.sVt + (int64_t)head * D * p.ldvt;
 
-    // zero the LDS padding that is read but never staged: K columns [D, DK*16), V^T rows [D, DT*32)
-    if (DK * 16 > D) {
-        for (int i = tid; i < KV; i += 256) *reinterpret_cast<uint4*>(Ks + i * KROW + DC * 16) = make_uint4(0, 0, 0, 0);
-    }
-    for (int i = tid; i < (DT * 32 - D) * (VROW / 8); i += 256) {
-        const int row = D + i / (VROW / 8), c = i % (VROW / 8);
-        *reinterpret_cast<uint2*>(Vs + row * VROW + c * 8) = make_uint2(0, 0);
+    // zero the LDS padding that is read but never staged (both stages): K columns [D, DK*16), V^T rows [D, DT*32)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        unsigned char* Ks0 = smem + st * kStageBytes;
+        unsigned char* Vs0 = Ks0 + KV * KROW;
+        if (DK * 16 > D) {
+            for (int i = tid; i < KV; i += 256) *reinterpret_cast<uint4*>(Ks0 + i * KROW + DC * 16) = make_uint4(0, 0, 0, 0);
+        }
+        for (int i = tid; i < (DT * 32 - D) * (VROW / 8); i += 256) {
+            const int row = D + i / (VROW / 8), c = i % (VROW / 8);
+            *reinterpret_cast<uint2*>(Vs0 + row * VROW + c * 8) = make_uint2(0, 0);
+        }
     }
 
     // Q fragments (B operand): lane (r, hh) element j = Q[q][16 s + 8 hh + j]
@@ -79,25 +85,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     float m_run = kNegBig, l_run = 0.f;
     const float c = p.scale_log2;
 
-    const int ntiles = (p.Nk + KV - 1) / KV;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int k0 = kt * KV;
-        __syncthreads();  // every wave is done reading the previous tile
-        // ---- stage K tile: [KV keys][D] ----
-        for (int id = tid; id < KV * DC; id += 256) {
+    // register staging of the NEXT tile: issued before the MFMAs of the current tile, written to the other LDS
+    // stage after them (one barrier per tile)
+    uint4 kreg[NKC], vreg[NVC];
+    auto load_kv = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NKC; ++u) {
+            const int id = tid + 256 * u;
             const int key = id / DC, ch = id - key * DC;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (k0 + key < p.Nk) v = *reinterpret_cast<const uint4*>(Kb + (int64_t)(k0 + key) * p.ldk + ch * 8);
-            *reinterpret_cast<uint4*>(Ks + key * KROW + ch * 16) = v;
+            if (id < KV * DC && k0 + key < p.Nk) v = *reinterpret_cast<const uint4*>(Kb + (int64_t)(k0 + key) * p.ldk + ch * 8);
+            kreg[u] = v;
         }
-        // ---- stage V^T tile: [D rows][KV keys], keys >= Nk zeroed ----
-        for (int id = tid; id < D * 8; id += 256) {
+#pragma unroll
+        for (int u = 0; u < NVC; ++u) {
+            const int id = tid + 256 * u;
             const int d = id >> 3, ch = id & 7;
             const int key = k0 + ch * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < p.Nk) {
+            if (id < D * 8 && key < p.Nk) {
                 v = *reinterpret_cast<const uint4*>(Vb + (int64_t)d * p.ldvt + key);
-                const int nv = p.Nk - key;  // valid elements in this chunk (>= 1)
+                const int nv = p.Nk - key;  // valid elements in this chunk (>= 1); keys >= Nk are zeroed
                 if (nv < 8) {
                     unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -108,11 +116,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                     v = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
-            unsigned char* dst = Vs + d * VROW + ch * 16;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
-            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(v.z, v.w);
+            vreg[u] = v;
         }
-        __syncthreads();
+    };
+    auto store_kv = [&](int st) {
+        unsigned char* Ks0 = smem + st * kStageBytes;
+        unsigned char* Vs0 = Ks0 + KV * KROW;
+#pragma unroll
+        for (int u = 0; u < NKC; ++u) {
+            const int id = tid + 256 * u;
+            const int key = id / DC, ch = id - key * DC;
+            if (id < KV * DC) *reinterpret_cast<uint4*>(Ks0 + key * KROW + ch * 16) = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NVC; ++u) {
+            const int id = tid + 256 * u;
+            const int d = id >> 3, ch = id & 7;
+            if (id < D * 8) {
+                unsigned char* dst = Vs0 + d * VROW + ch * 16;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(vreg[u].x, vreg[u].y);
+                *reinterpret_cast<uint2*>(dst + 8) = make_uint2(vreg[u].z, vreg[u].w);
+            }
+        }
+    };
+
+    const int ntiles = (p.Nk + KV - 1) / KV;
+    load_kv(0);
+    __syncthreads();  // padding zero-fill visible before the first stage is written around it
+    store_kv(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * KV;
+        const unsigned char* Ks = smem + (kt & 1) * kStageBytes;
+        const unsigned char* Vs = Ks + KV * KROW;
+        if (kt + 1 < ntiles) load_kv(k0 + KV);
 
         // ---- S^T = K Q^T for two 32-key tiles ----
         f32x16 st[2];
@@ -157,10 +194,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                 psum += pv;
             }
         l_run = l_run * alpha + psum;
+        if (!__all(alpha == 1.0f)) {  // wave-uniform: the running max of every query of this wave is unchanged -> no rescale
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) ot[t][i] *= alpha;
+                for (int i = 0; i < 16; ++i) ot[t][i] *= alpha;
+        }
         // P^T -> bf16 B fragments: k-step ks = 2 t + s uses registers 8 s .. 8 s + 7 of tile t
         bf16x8 pf[4];
 #pragma unroll
@@ -187,6 +226,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                 ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[dt], 0, 0, 0);
             }
         }
+        if (kt + 1 < ntiles) store_kv((kt + 1) & 1);  // that stage was last read in iteration kt-1
+        __syncthreads();
     }
 
     // ---- normalise and store: lane owns query q, registers hold d = 32 dt + 8 g + 4 hh + i ----
@@ -212,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 template <int D>
 int launch_attn(const AttnParams& p, int B, int H, hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DT = (D + 31) / 32;
-    const size_t smem = (size_t)KV * (2 * DK + 1) * 16 + (size_t)DT * 32 * VROW;
+    const size_t smem = 2 * ((size_t)KV * (2 * DK + 1) * 16 + (size_t)DT * 32 * VROW);  // two pipeline stages
     dim3 grid((p.Nq + 127) / 128, H, B);
     attn_fwd_kernel<D><<<grid, 256, smem, s>>>(p);
     hipError_t e = hipGetLastError();

@@ -16,6 +16,7 @@
 // For conv3x3 the GEMM row m is the output pixel (b, oy, ox), k = (ky*3+kx)*Cin + c; the A tile is
 // gathered on the fly (zero padding, stride 2, fused nearest-2x upsample) -- no im2col buffer.
 #include "gmd_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +34,9 @@ struct GemmParams {
     float alpha;
     int act;
     int out_f32;
+    unsigned a_bytes, w_bytes;  // extents of the A / W operands (one batch slab) for the buffer descriptors
+    int ksplit;          // > 1: grid z splits K; raw fp32 partial sums go to `ws` [ksplit][M][N], epilogue in splitk_reduce
+    float* ws;
     // conv3x3 geometry (CONV instantiations only)
     int Hin, Win, Cin, Hout, Wout, stride, upsample, pad_lo;
 };
@@ -84,6 +88,70 @@ __device__ __forceinline__ int64_t a_offset(const GemmParams& p, const RowCtx& r
 
 __device__ __forceinline__ float apply_act(float v, int act) { return act == GMD_ACT_SILU ? silu_f(v) : v; }
 
+// Fused epilogue for 8 consecutive columns n..n+7 of row m (bf16 activations): alpha, bias, per-group row
+// bias, residual, activation, then a 16-byte store (scalar stores on ragged / unaligned edges).
+__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int m, int n, float (&v)[8]) {
+    const bool vec_ok = (p.ldc % 8 == 0) && (p.sC % 8 == 0) && (p.residual == nullptr || (p.ldr % 8 == 0 && p.sR % 8 == 0));
+    const int nvalid = p.N - n < 8 ? p.N - n : 8;
+    const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
+    const bf16_t* res = p.residual ? (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n : nullptr;
+    float rv[8];
+    if (res) {
+        if (nvalid == 8 && vec_ok) load_vec(res, rv);
+        else
+            for (int j = 0; j < 8; ++j) rv[j] = j < nvalid ? bf16_to_f32(res[j]) : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < nvalid) {
+            float x = v[j] * p.alpha;
+            if (p.bias) x += p.bias[n + j];
+            if (rb) x += rb[n + j];
+            if (res) x += rv[j];
+            v[j] = apply_act(x, p.act);
+        }
+    }
+    const int64_t coff = (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+    if (p.out_f32) {
+        float* o = (float*)p.C + coff;
+        if (nvalid == 8 && p.ldc % 4 == 0 && p.sC % 4 == 0) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            for (int j = 0; j < nvalid; ++j) o[j] = v[j];
+        }
+    } else {
+        bf16_t* o = (bf16_t*)p.C + coff;
+        if (nvalid == 8 && vec_ok) store_vec(o, v);
+        else
+            for (int j = 0; j < nvalid; ++j) o[j] = f32_to_bf16(v[j]);
+    }
+}
+
+// split-K: sum the fp32 partial slabs ws[s][m][n] in a fixed order, then the fused epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    const int NC = (p.N + 7) / 8;
+    const int64_t total = (int64_t)p.M * NC;
+    const int64_t slab = (int64_t)p.M * p.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / NC), n = (int)(i - (int64_t)m * NC) * 8;
+        const int nvalid = p.N - n < 8 ? p.N - n : 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        const float* src = p.ws + (int64_t)m * p.N + n;
+        for (int s = 0; s < p.ksplit; ++s, src += slab) {
+            if (nvalid == 8 && p.N % 4 == 0) {
+                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            } else {
+                for (int j = 0; j < nvalid; ++j) v[j] += src[j];
+            }
+        }
+        epilogue_store8(p, 0, m, n, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------
@@ -93,30 +161,78 @@ constexpr int BK = 64;  // bf16 elements per K step = 128 bytes = 8 chunks of 16
 // 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups of a 16x16x32 fragment conflict-free
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <bool CONV, int BM, int BN>
+template <int V> struct IntC { static constexpr int value = V; };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0xFFFF0000u;  // byte offset beyond every buffer (extents are checked < kOOB on the host)
+
+// Operand addressing of the bf16 kernel: every staging slot keeps ONE 32-bit byte offset into a raw buffer
+// resource; rows beyond M/N and conv padding taps hold kOOB, for which the buffer load returns zeros -- no
+// branches and no 64-bit arithmetic in the K loop.  For conv3x3 the offsets are recomputed only when the
+// K loop crosses into the next filter tap (every Cin/64 steps).
+template <bool CONV>
+__device__ __forceinline__ unsigned conv_tap_offset(const GemmParams& p, bool valid, int b, int oy, int ox, int ky, int kx, int chunk) {
+    if (!valid) return kOOB;
+    int iy, ix;
+    if (p.upsample) {
+        const int uy = oy + ky - 1, ux = ox + kx - 1;
+        if (uy < 0 || ux < 0 || uy >= 2 * p.Hin || ux >= 2 * p.Win) return kOOB;
+        iy = uy >> 1;
+        ix = ux >> 1;
+    } else {
+        iy = oy * p.stride + ky - p.pad_lo;
+        ix = ox * p.stride + kx - p.pad_lo;
+        if (iy < 0 || ix < 0 || iy >= p.Hin || ix >= p.Win) return kOOB;
+    }
+    return (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin) * 2u + (unsigned)chunk * 16u;
+}
+
+// PF = register prefetch distance in K steps: the global loads of tile kt+PF are issued before the MFMAs of
+// tile kt and are written to LDS at the end of iteration kt+PF-1, i.e. they have PF whole iterations to land.
+template <bool CONV, int BM, int BN, int PF>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int NA = BM / 32, NW = BN / 32;  // staging slots per thread
     constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave along M / N (wave tile = BM/2 x BN/2)
-    constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kStage = (BM + BN) * 128;  // bytes per pipeline stage: A tile then W tile
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int z = blockIdx.z;
-    const bf16_t* A = (const bf16_t*)p.A + (int64_t)z * p.sA;
-    const bf16_t* W = (const bf16_t*)p.W + (int64_t)z * p.sW;
+    // grid z = batch index (plain batched GEMM) or K-split index (p.ksplit > 1, batch == 1)
+    const int z = p.ksplit > 1 ? 0 : blockIdx.z;
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const bf16_t*)p.A + (int64_t)z * p.sA), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const bf16_t*)p.W + (int64_t)z * p.sW), 0, p.w_bytes, 0x00020000);
 
     const int chunk = tid & 7, srow = tid >> 3;  // staging: 8 chunks per row, 32 rows per pass
-    RowCtx ra[NA];
-    int64_t wbase[NW];
+    unsigned aoff[NA], woff[NW];                  // byte offsets of (slot row, current tap, channel 0)
+    int pb[NA], py[NA], px[NA];                   // conv: output pixel of each A slot
+    bool pv[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = make_row<CONV>(p, m0 + srow + 32 * i);
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + srow + 32 * i;
+        pv[i] = m < p.M;
+        pb[i] = py[i] = px[i] = 0;
+        if (CONV) {
+            if (pv[i]) {
+                const int hw = p.Hout * p.Wout;
+                pb[i] = m / hw;
+                const int rem = m - pb[i] * hw;
+                py[i] = rem / p.Wout;
+                px[i] = rem - py[i] * p.Wout;
+            }
+            aoff[i] = kOOB;
+        } else {
+            aoff[i] = pv[i] ? (unsigned)m * (unsigned)p.lda * 2u + (unsigned)chunk * 16u : kOOB;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int n = n0 + srow + 32 * i;
-        wbase[i] = n < p.N ? (int64_t)n * p.ldw : -1;
+        woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u + (unsigned)chunk * 16u : kOOB;
     }
 
     f32x4 acc[TM][TN];
@@ -125,41 +241,50 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rga[NA], rgw[NW];
-    const int nk = p.K / BK;
-    int tap = 0, c0 = 0;  // conv: running (tap, channel) of the K step being LOADED
+    u32x4 rga[PF][NA], rgw[PF][NW];
+    const int nk_total = p.K / BK;
+    const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * per;
+    const int nk = (kt_begin + per <= nk_total ? per : nk_total - kt_begin);  // K steps of this block (may be <= 0)
+    int tap = 0, c0 = 0;     // conv: (tap, channel) of the K step being LOADED
+    bool newtap = true;
+    if (CONV) {
+        const int kb = kt_begin * BK;
+        tap = kb / p.Cin;
+        c0 = kb - tap * p.Cin;
+    }
 
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-        const int ky = tap / 3, kx = tap - ky * 3;
+    auto load_tile = [&](auto SET, int kt) {
+        constexpr int S = decltype(SET)::value;
+        const unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
+        unsigned abytes = kbytes;  // gemm: k offset; conv: channel offset inside the tap
+        if (CONV) {
+            if (newtap) {  // wave-uniform: once per tap
+                const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int64_t off = a_offset<CONV>(p, ra[i], k0, ky, kx, c0);
-            rga[i] = off >= 0 ? *reinterpret_cast<const uint4*>(A + off + chunk * 8) : make_uint4(0, 0, 0, 0);
+                for (int i = 0; i < NA; ++i) aoff[i] = conv_tap_offset<CONV>(p, pv[i], pb[i], py[i], px[i], ky, kx, chunk);
+                newtap = false;
+            }
+            abytes = (unsigned)c0 * 2u;
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-            rgw[i] = wbase[i] >= 0 ? *reinterpret_cast<const uint4*>(W + wbase[i] + k0 + chunk * 8) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < NA; ++i) rga[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[i] + abytes, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) rgw[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, woff[i] + kbytes, 0, 0);
         if (CONV) {
             c0 += BK;
-            if (c0 >= p.Cin) { c0 = 0; ++tap; }
+            if (c0 >= p.Cin) { c0 = 0; ++tap; newtap = true; }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(smem + buf * kStage + lds_off(srow + 32 * i, chunk)) = rga[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(smem + buf * kStage + lds_off(srow + 32 * i, chunk)) = rga[S][i];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) *reinterpret_cast<uint4*>(smem + buf * kStage + BM * 128 + lds_off(srow + 32 * i, chunk)) = rgw[i];
+        for (int i = 0; i < NW; ++i) *reinterpret_cast<u32x4*>(smem + buf * kStage + BM * 128 + lds_off(srow + 32 * i, chunk)) = rgw[S][i];
     };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 a[TM], b[TN];
@@ -173,77 +298,103 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane = (m, 4 n's)
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+    };
+
+    if (nk > 0) {
+        if constexpr (PF == 1) {
+            load_tile(IntC<0>{}, 0);
+            store_tile(IntC<0>{}, 0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < nk) load_tile(IntC<0>{}, kt + 1);
+                compute(cur);
+                if (kt + 1 < nk) store_tile(IntC<0>{}, cur ^ 1);
+                __syncthreads();
+            }
+        } else {
+            // tile kt lives in LDS[kt&1]; tile kt+1 is in flight in register set (kt+1)&1; tile kt+2 is issued
+            // into set kt&1 at the top of iteration kt (that set was drained to LDS at the end of iteration kt-1)
+            load_tile(IntC<0>{}, 0);
+            if (nk > 1) load_tile(IntC<1>{}, 1);
+            store_tile(IntC<0>{}, 0);
+            __syncthreads();
+            auto iter = [&](auto SET, int kt) {
+                constexpr int S = decltype(SET)::value;  // == kt & 1
+                if (kt + 2 < nk) load_tile(IntC<S>{}, kt + 2);
+                compute(S);
+                if (kt + 1 < nk) store_tile(IntC<S ^ 1>{}, S ^ 1);
+                __syncthreads();
+            };
+            int kt = 0;
+            for (; kt + 1 < nk; kt += 2) {
+                iter(IntC<0>{}, kt);
+                iter(IntC<1>{}, kt + 1);
+            }
+            if (kt < nk) iter(IntC<0>{}, kt);
+        }
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32, 64 rows per pass) -> coalesced fused store ----
-    float* Cs = reinterpret_cast<float*>(smem);
-    constexpr int PASSES = BM / 64;  // BM=128: wave row `h` per pass; BM=64: one pass, both wave rows
-    constexpr int CH = BN / 8;
-    const bool vec_ok = (p.ldc % 8 == 0) && (p.sC % 8 == 0) && (p.residual == nullptr || (p.ldr % 8 == 0 && p.sR % 8 == 0));
-    for (int h = 0; h < PASSES; ++h) {
-        if (PASSES == 1 || wr == h) {
-            const int rbase = PASSES == 1 ? wr * (BM / 2) : 0;
+    // ---- epilogue straight from registers.  The MFMA operands are swapped (W fragment as A, activation fragment
+    // as B), so by the C/D layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds FOUR CONSECUTIVE output
+    // columns n of ONE row m: bias/residual/activation are applied in registers and each lane stores 8 bytes
+    // (bf16) or 16 bytes (fp32 / split-K partials) -- no LDS round trip, no barrier.
+    const bool vec_c = (p.ldc % 4 == 0) && (p.sC % 4 == 0);
+    const bool vec_r = p.residual != nullptr && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * (BM / 2) + i * 16 + frow;
+        if (m >= p.M) continue;
+        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // C/D layout of mfma_f32_16x16x32: row = 4*(lane>>4)+reg, col = lane&15
-                        const int ml = rbase + i * 16 + fq * 4 + r;
-                        const int nl = wc * (BN / 2) + j * 16 + frow;
-                        Cs[ml * LDC + nl] = acc[i][j][r];
-                    }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < 64 * CH; idx += 256) {
-            const int ml = idx / CH, ch = idx - ml * CH;
-            const int m = m0 + h * 64 + ml, n = n0 + ch * 8;
-            if (m >= p.M || n >= p.N) continue;
-            float v[8];
-            const float4 v0 = *reinterpret_cast<const float4*>(Cs + ml * LDC + ch * 8);
-            const float4 v1 = *reinterpret_cast<const float4*>(Cs + ml * LDC + ch * 8 + 4);
-            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-            const int nvalid = p.N - n < 8 ? p.N - n : 8;
-            const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
-            const bf16_t* res = p.residual ? (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n : nullptr;
-            float rv[8];
-            if (res) {
-                if (nvalid == 8 && vec_ok) load_vec(res, rv);
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * (BN / 2) + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            const int nvalid = p.N - n < 4 ? p.N - n : 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.ksplit > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
+                float* o = p.ws + ((int64_t)ks * p.M + m) * p.N + n;
+                if (nvalid == 4 && p.N % 4 == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                 else
-                    for (int j = 0; j < 8; ++j) rv[j] = j < nvalid ? bf16_to_f32(res[j]) : 0.f;
+                    for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+                continue;
+            }
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) {
+                const bf16_t* res = (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n;
+                if (nvalid == 4 && vec_r) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(res);
+                    rv[0] = __uint_as_float(w.x << 16); rv[1] = __uint_as_float(w.x & 0xffff0000u);
+                    rv[2] = __uint_as_float(w.y << 16); rv[3] = __uint_as_float(w.y & 0xffff0000u);
+                } else {
+                    for (int e = 0; e < nvalid; ++e) rv[e] = bf16_to_f32(res[e]);
+                }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < nvalid) {
-                    float x = v[j] * p.alpha;
-                    if (p.bias) x += p.bias[n + j];
-                    if (rb) x += rb[n + j];
-                    if (res) x += rv[j];
-                    v[j] = apply_act(x, p.act);
+            for (int e = 0; e < 4; ++e) {
+                if (e < nvalid) {
+                    float x = v[e] * p.alpha;
+                    if (p.bias) x += p.bias[n + e];
+                    if (rb) x += rb[n + e];
+                    x += rv[e];
+                    v[e] = apply_act(x, p.act);
                 }
             }
             const int64_t coff = (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
             if (p.out_f32) {
                 float* o = (float*)p.C + coff;
-                if (nvalid == 8 && p.ldc % 4 == 0 && p.sC % 4 == 0) {
-                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                } else {
-                    for (int j = 0; j < nvalid; ++j) o[j] = v[j];
-                }
+                if (nvalid == 4 && vec_c) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int e = 0; e < nvalid; ++e) o[e] = v[e];
             } else {
                 bf16_t* o = (bf16_t*)p.C + coff;
-                if (nvalid == 8 && vec_ok) store_vec(o, v);
+                if (nvalid == 4 && vec_c) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 else
-                    for (int j = 0; j < nvalid; ++j) o[j] = f32_to_bf16(v[j]);
+                    for (int e = 0; e < nvalid; ++e) o[e] = f32_to_bf16(v[e]);
             }
         }
-        if (h + 1 < PASSES) __syncthreads();
     }
 }
 
@@ -315,24 +466,76 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
+struct Plan {
+    int bm, bn, pf, ksplit;
+};
+
+// Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
+// 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
+// deep K (the 8x8 / 16x16 UNet levels: K up to 23040) are split along K.
+Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
+    Plan pl{64, 64, 1, 1};
+    if (M >= 96 && N >= 96) {
+        pl.bm = 128;
+        pl.bn = (N % 160 == 0) ? 160 : 128;
+    }
+    const char* f = getenv("GMD_GEMM_FORCE");  // "bm,bn,pf,ksplit" (0 = keep heuristic) -- tuning experiments only
+    int fbm = 0, fbn = 0, fpf = 0, fks = 0;
+    if (f) sscanf(f, "%d,%d,%d,%d", &fbm, &fbn, &fpf, &fks);
+    if (fbm && fbn) { pl.bm = fbm; pl.bn = fbn; }
+    if (fpf) pl.pf = fpf;
+    const int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
+    const int nk = K / BK;
+    if (batch == 1 && tiles < 200 && nk >= 8) {
+        int ks = (int)((384 + tiles - 1) / tiles);
+        if (ks > nk / 4) ks = nk / 4;
+        if (ks > 16) ks = 16;
+        if (ks > 1 && (int64_t)ks * M * N * (int64_t)sizeof(float) <= ws_bytes) pl.ksplit = ks;
+    }
+    if (fks) pl.ksplit = ((int64_t)fks * M * N * (int64_t)sizeof(float) <= ws_bytes && batch == 1) ? fks : 1;
+    return pl;
+}
+
+template <bool CONV, int BM, int BN, int PF>
+hipError_t launch_bf16(const GemmParams& p, int gz, hipStream_t s) {
+    constexpr size_t smem = 2 * (BM + BN) * 128;
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
+    if (smem > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, BM, BN, PF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, gz);
+    gemm_bf16_kernel<CONV, BM, BN, PF><<<grid, 256, smem, s>>>(p);
+    return hipGetLastError();
+}
+
 template <bool CONV>
-int launch(const GemmParams& p, int dtype, int batch, hipStream_t s, const char* name) {
+int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+    hipError_t e = hipSuccess;
     if (dtype == GMD_BF16) {
-        const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-        if (tiles128 >= 192 && p.N > 64) {
-            dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, batch);
-            const size_t smem = 2 * (128 + 128) * 128;  // 64 KiB main-loop buffers (epilogue staging reuses 33 KiB of it)
-            gemm_bf16_kernel<CONV, 128, 128><<<grid, 256, smem, s>>>(p);
-        } else {
-            dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
-            const size_t smem = 2 * (64 + 64) * 128;  // main-loop buffers (32 KiB) > epilogue staging (17 KiB)
-            gemm_bf16_kernel<CONV, 64, 64><<<grid, 256, smem, s>>>(p);
+        const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0);
+        p.ksplit = pl.ksplit;
+        p.ws = (float*)ws;
+        const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
+        if (pl.bm == 128 && pl.bn == 160) e = pl.pf == 1 ? launch_bf16<CONV, 128, 160, 1>(p, gz, s) : launch_bf16<CONV, 128, 160, 2>(p, gz, s);
+        else if (pl.bm == 128 && pl.bn == 128) e = pl.pf == 1 ? launch_bf16<CONV, 128, 128, 1>(p, gz, s) : launch_bf16<CONV, 128, 128, 2>(p, gz, s);
+        else e = pl.pf == 1 ? launch_bf16<CONV, 64, 64, 1>(p, gz, s) : launch_bf16<CONV, 64, 64, 2>(p, gz, s);
+        if (e == hipSuccess && pl.ksplit > 1) {
+            const int64_t total = (int64_t)p.M * ((p.N + 7) / 8);
+            int64_t g = (total + 255) / 256;
+            if (g > 4096) g = 4096;
+            splitk_reduce_kernel<<<(int)g, 256, 0, s>>>(p);
+            e = hipGetLastError();
         }
     } else {
+        p.ksplit = 1;
+        p.ws = nullptr;
         dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
         gemm_f32_kernel<CONV><<<grid, 256, 0, s>>>(p);
+        e = hipGetLastError();
     }
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gmd_set_error("%s: launch failed: %s", name, hipGetErrorString(e));
         return GMD_ERR_LAUNCH;
@@ -347,7 +550,7 @@ extern "C" {
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype, int M, int N, int K, int64_t lda,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,
                 const float* rowbias, int rows_per_group, const void* residual, int64_t ldr, int64_t strideR, float alpha,
-                int act, gmd_stream_t stream) {
+                int act, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_gemm_nt: bad dtype %d", dtype);
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
     GMD_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gmd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
@@ -366,15 +569,20 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = strideA; p.sW = strideW; p.sC = strideC;
+    {
+        const int64_t ab = ((int64_t)(M - 1) * lda + K) * 2, wb = ((int64_t)(N - 1) * ldw + K) * 2;
+        GMD_REQUIRE(dtype != GMD_BF16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_gemm_nt: operand slab larger than 4 GiB");
+        p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    }
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.residual = residual; p.ldr = ldr; p.sR = strideR; p.alpha = alpha; p.act = act;
     p.out_f32 = out_dtype == GMD_F32;
-    return launch<false>(p, dtype, batch, (hipStream_t)stream, "gmd_gemm_nt");
+    return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
 }
 
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
                 int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, const void* residual,
-                gmd_stream_t stream) {
+                void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_conv3x3: bad dtype %d", dtype);
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_conv3x3: out_dtype must be F32 or the input dtype");
     GMD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "gmd_conv3x3: bad shape");
@@ -395,11 +603,16 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     GemmParams p{};
     p.A = X; p.W = Wt; p.C = Y; p.M = (int)M; p.N = Cout; p.K = 9 * Cin;
     p.lda = Cin; p.ldw = 9 * (int64_t)Cin; p.ldc = Cout;
+    {
+        const int64_t ab = (int64_t)B * Hin * Win * Cin * 2, wb = (int64_t)Cout * 9 * Cin * 2;
+        GMD_REQUIRE(dtype != GMD_BF16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_conv3x3: tensor larger than 4 GiB");
+        p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    }
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = Hout * Wout;
     p.residual = residual; p.ldr = Cout; p.alpha = 1.0f; p.act = GMD_ACT_NONE;
     p.out_f32 = out_dtype == GMD_F32;
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.upsample = upsample; p.pad_lo = pad_lo;
-    return launch<true>(p, dtype, 1, (hipStream_t)stream, "gmd_conv3x3");
+    return launch<true>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
 }
 
 }  // extern "C"

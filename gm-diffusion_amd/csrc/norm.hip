@@ -36,7 +36,17 @@ __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const T* __restric
 #pragma unroll
         for (int j = 0; j < V; ++j) a[j] = q[j] = 0.0f;
         if (py < PY && chunk < CV) {
-            for (int64_t p = p0 + py; p < p1; p += PY) {
+            int64_t p = p0 + py;
+            for (; p + PY < p1; p += 2 * PY) {  // two independent 16-byte loads in flight per thread
+                float v[V], w[V];
+                load_vec(Xb + p * C + (int64_t)chunk * V, v);
+                load_vec(Xb + (p + PY) * C + (int64_t)chunk * V, w);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { a[j] += v[j]; q[j] += v[j] * v[j]; }
+#pragma unroll
+                for (int j = 0; j < V; ++j) { a[j] += w[j]; q[j] += w[j] * w[j]; }
+            }
+            if (p < p1) {
                 float v[V];
                 load_vec(Xb + p * C + (int64_t)chunk * V, v);
 #pragma unroll
@@ -207,7 +217,7 @@ inline int grid_for(int64_t n) {
 extern "C" {
 
 int gmd_groupnorm_nsplit(int64_t HW) {
-    int64_t n = HW / 128;
+    int64_t n = HW / 32;  // >= 32 pixels per block; B * nsplit blocks should cover the 256 CUs several times
     if (n < 1) n = 1;
     if (n > 256) n = 256;
     return (int)n;

@@ -36,8 +36,8 @@ SIGNATURES = {
     "gmd_cfg_std_ratio": [P, I, L, F, P, P],
     "gmd_pack_unet_input": [P, I, P, I, I, L, I, P, I, I, P],
     "gmd_unpack_nchw": [P, I, L, I, I, L, P, P],
-    "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, P, L, L, F, I, P],
-    "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, P, P],
+    "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, P, L, L, F, I, P, L, P],
+    "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, P, P, L, P],
     "gmd_attention": [P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, P],
     "gmd_softmax_rows": [P, L, P, I, L, L, I, F, P],
     "gmd_groupnorm_nsplit": [L],

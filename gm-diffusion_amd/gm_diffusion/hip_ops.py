@@ -52,6 +52,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_WS = {}
+WORKSPACE_BYTES = 96 << 20
+
+
+def _workspace(device):
+    """Persistent float32 scratch (per device) that lets under-filled GEMM/conv launches split K."""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = _WS[device] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def _f32(t, name):
     if t is not None and t.dtype != torch.float32:
         raise HipExtensionError(f"{name} must be float32")
@@ -92,11 +104,12 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
         sR = M * N if residual.dim() == 3 else 0
     if bias is not None and bias.numel() != N:
         raise HipExtensionError("gemm_nt: bias must have N elements")
+    ws = _workspace(a.device) if batch == 1 else None
     tm = profiling.active()
     t0 = tm.begin() if tm else None
     check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, dtype_code(out_dtype), M, N, K, K, K, ldc, batch, sA, sW, sC,
                             _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")), rows_per_group,
-                            _ptr(residual), N, sR, float(alpha), act, _stream()), "gmd_gemm_nt")
+                            _ptr(residual), N, sR, float(alpha), act, _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_gemm_nt")
     if tm:
         es = a.element_size()
         tm.end("gemm_nt", 2.0 * batch * M * N * K, batch * (M * K + N * K + M * N) * es, t0)
@@ -121,11 +134,12 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
         raise HipExtensionError("conv3x3: residual shape/dtype mismatch")
     if rowbias is not None and rowbias.numel() != B * cout:
         raise HipExtensionError("conv3x3: rowbias must be [B, Cout]")
+    ws = _workspace(x.device)
     tm = profiling.active()
     t0 = tm.begin() if tm else None
     check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, H, W, cin, cout,
                             stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")),
-                            _ptr(residual), _stream()), "gmd_conv3x3")
+                            _ptr(residual), _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_conv3x3")
     if tm:
         tm.end("conv3x3", 2.0 * B * ho * wo * cout * 9 * cin, x.numel() * x.element_size() + w.numel() * w.element_size()
                + y.numel() * y.element_size(), t0)
@@ -377,5 +391,5 @@ def gemm_raw(a_ptr, w_ptr, c_ptr, dtype, out_dtype, M, N, K, lda, ldw, ldc, batc
     a_ptr/w_ptr/c_ptr are integer device addresses; the caller keeps the owning tensors alive."""
     _dev(bias)
     check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, dtype_code(dtype), dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
-                            sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, None, 0, 0, float(alpha), act, _stream()),
+                            sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, None, 0, 0, float(alpha), act, None, 0, _stream()),
           "gmd_gemm_nt")

@@ -139,13 +139,15 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
  * bias: float32 [N] or NULL.  rowbias: float32 [ceil(M/rows_per_group), N] or NULL, added to rows
  * of group m/rows_per_group (ResnetBlock2D time-embedding add).  residual: `dtype` [M,N] ld ldr or NULL.
  * Requirements: K % 64 == 0 (BF16) / K % 4 == 0 (F32); lda, ldw multiples of 8 (BF16) / 4 (F32) elements;
- * base pointers 16-byte aligned.  nn.Linear / conv1x1 / attention score products. */
+ * base pointers 16-byte aligned.  nn.Linear / conv1x1 / attention score products.
+ * workspace (optional, float32 scratch of workspace_bytes): lets launches that cannot fill the chip split K
+ * (deterministic slab reduction, no atomics); with NULL / too small a workspace K is not split. */
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 int M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
                 int batch, int64_t strideA, int64_t strideW, int64_t strideC,
                 const float* bias, const float* rowbias, int rows_per_group,
                 const void* residual, int64_t ldr, int64_t strideR,
-                float alpha, int act, gmd_stream_t stream);
+                float alpha, int act, void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
 
 /* 3x3 convolution, padding 1, as an implicit GEMM over channels-last data.
  * X: [B,Hin,Win,Cin]; Wt: [Cout, 9*Cin] with k = (ky*3+kx)*Cin + c; Y: [B,Hout,Wout,Cout].
@@ -156,7 +158,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype,
                 int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode,
                 const float* bias, const float* rowbias, const void* residual,
-                gmd_stream_t stream);
+                void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
 
 /* Flash-style attention, bf16 MFMA: O = softmax(scale * Q K^T) V per (batch, head).
  * Q: [B,Nq,*] head h at columns h*D..h*D+D, row stride ldq; K likewise (ldk);
