@@ -29,6 +29,7 @@ struct GemmParams {
     const float* bias;
     const float* rowbias;
     int rows_per_group;
+    int64_t ldrb;        // row stride of rowbias (>= N)
     const void* residual;
     int64_t ldr, sR;
     float alpha;
@@ -93,7 +94,7 @@ __device__ __forceinline__ float apply_act(float v, int act) { return act == GMD
 __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int m, int n, float (&v)[8]) {
     const bool vec_ok = (p.ldc % 8 == 0) && (p.sC % 8 == 0) && (p.residual == nullptr || (p.ldr % 8 == 0 && p.sR % 8 == 0));
     const int nvalid = p.N - n < 8 ? p.N - n : 8;
-    const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
+    const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
     const bf16_t* res = p.residual ? (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n : nullptr;
     float rv[8];
     if (res) {
@@ -207,7 +208,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const bf16_t*)p.W + (int64_t)z * p.sW), 0, p.w_bytes, 0x00020000);
 
-    const int chunk = tid & 7, srow = tid >> 3;  // staging: 8 chunks per row, 32 rows per pass
+    const int srow = tid >> 3;  // staging: 8 chunks per row, 32 rows per pass
+    // register staging writes logical chunk `tid&7` at its swizzled LDS position; the LDS-DMA path (PF == 0) can
+    // only write lane-linear, so there the SOURCE chunk is swizzled instead (same involution, rows srow + 32 i
+    // share (row>>1)&7)
+    const int chunk = PF == 0 ? ((tid & 7) ^ ((srow >> 1) & 7)) : (tid & 7);
     unsigned aoff[NA], woff[NW];                  // byte offsets of (slot row, current tap, channel 0)
     int pb[NA], py[NA], px[NA];                   // conv: output pixel of each A slot
     bool pv[NA];
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 rga[PF][NA], rgw[PF][NW];
+    u32x4 rga[PF > 0 ? PF : 1][NA], rgw[PF > 0 ? PF : 1][NW];
     const int nk_total = p.K / BK;
     const int per = (nk_total + p.ksplit - 1) / p.ksplit;
     const int kt_begin = ks * per;
@@ -302,8 +307,67 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         }
     };
 
+    // LDS-DMA: buffer_load ... lds writes 64 lanes x 16 B = 8 tile rows per wave instruction at the wave-uniform LDS
+    // address in M0.  Issued through inline asm so that hipcc does not serialise it against the ds_reads of the
+    // OTHER stage (with the builtin it waits vmcnt(0) before every LDS read); completion is awaited by the explicit
+    // s_waitcnt vmcnt(0) in front of the stage-release barrier.
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    u32x4 dA, dW;  // hand-built buffer descriptors (base, base_hi | stride 0, num_records, flags)
+    {
+        const uint64_t ba = (uint64_t)((const bf16_t*)p.A + (int64_t)z * p.sA), bw = (uint64_t)((const bf16_t*)p.W + (int64_t)z * p.sW);
+        dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+        dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+    }
+    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(lds_addr), "s"(desc)
+                     : "memory");
+    };
+    auto dma_tile = [&](int kt, int buf) {
+        const unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
+        unsigned abytes = kbytes;
+        if (CONV) {
+            if (newtap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) aoff[i] = conv_tap_offset<CONV>(p, pv[i], pb[i], py[i], px[i], ky, kx, chunk);
+                newtap = false;
+            }
+            abytes = (unsigned)c0 * 2u;
+        }
+        const unsigned stage = lds_base + (unsigned)buf * kStage + (unsigned)wuni * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (32 * 128), aoff[i] + abytes);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) dma16(dW, stage + BM * 128 + i * (32 * 128), woff[i] + kbytes);
+        if (CONV) {
+            c0 += BK;
+            if (c0 >= p.Cin) { c0 = 0; ++tap; newtap = true; }
+        }
+    };
+    auto dma_wait_and_release = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs have landed in LDS ...
+        __syncthreads();                                  // ... and every wave's; all reads of the other stage are done
+    };
+
     if (nk > 0) {
-        if constexpr (PF == 1) {
+        if constexpr (PF == 0) {
+            // two LDS stages; the DMA of tile kt+1 is in flight while tile kt is multiplied; __syncthreads() waits for
+            // this wave's DMAs (vmcnt(0)) and then for every wave, which also releases stage kt&1 for the next DMA
+            dma_tile(0, 0);
+            dma_wait_and_release();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
+                compute(cur);
+                dma_wait_and_release();
+            }
+        } else if constexpr (PF == 1) {
             load_tile(IntC<0>{}, 0);
             store_tile(IntC<0>{}, 0);
             __syncthreads();
@@ -343,11 +407,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     // (bf16) or 16 bytes (fp32 / split-K partials) -- no LDS round trip, no barrier.
     const bool vec_c = (p.ldc % 4 == 0) && (p.sC % 4 == 0);
     const bool vec_r = p.residual != nullptr && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
+    const bool vec_n = (p.N % 4 == 0);
+    const bool vec_rb = vec_n && (p.ldrb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0);
+    // per-column bias of this lane's TN column groups, loaded once (16-byte loads) ahead of the row loop
+    float bz[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * (BN / 2) + j * 16 + fq * 4;
+        bz[j][0] = bz[j][1] = bz[j][2] = bz[j][3] = 0.f;
+        if (p.bias && p.ksplit <= 1 && n < p.N) {
+            if (n + 4 <= p.N && vec_n) {
+                const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
+                bz[j][0] = t.x; bz[j][1] = t.y; bz[j][2] = t.z; bz[j][3] = t.w;
+            } else {
+                for (int e = 0; e < 4; ++e) if (n + e < p.N) bz[j][e] = p.bias[n + e];
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wr * (BM / 2) + i * 16 + frow;
         if (m >= p.M) continue;
-        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
+        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wc * (BN / 2) + j * 16 + fq * 4;
@@ -356,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.ksplit > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
                 float* o = p.ws + ((int64_t)ks * p.M + m) * p.N + n;
-                if (nvalid == 4 && p.N % 4 == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (nvalid == 4 && vec_n) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                 else
                     for (int e = 0; e < nvalid; ++e) o[e] = v[e];
                 continue;
@@ -372,16 +453,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
                     for (int e = 0; e < nvalid; ++e) rv[e] = bf16_to_f32(res[e]);
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (e < nvalid) {
-                    float x = v[e] * p.alpha;
-                    if (p.bias) x += p.bias[n + e];
-                    if (rb) x += rb[n + e];
-                    x += rv[e];
-                    v[e] = apply_act(x, p.act);
+            if (rb) {
+                if (nvalid == 4 && vec_rb) {
+                    const float4 t = *reinterpret_cast<const float4*>(rb + n);
+                    rv[0] += t.x; rv[1] += t.y; rv[2] += t.z; rv[3] += t.w;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) rv[e] += rb[n + e];
                 }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[j][e] + rv[e], p.act);
             const int64_t coff = (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
             if (p.out_f32) {
                 float* o = (float*)p.C + coff;
@@ -450,7 +531,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + ty * 4 + i;
         if (m >= p.M) continue;
-        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
+        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
         const float* res = p.residual ? (const float*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr : nullptr;
         float* o = (float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc;
 #pragma unroll
@@ -474,7 +555,7 @@ struct Plan {
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
 // deep K (the 8x8 / 16x16 UNet levels: K up to 23040) are split along K.
 Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
-    Plan pl{64, 64, 1, 1};
+    Plan pl{64, 64, 0, 1};  // pf 0 = LDS-DMA pipeline (fastest measured); 1/2 = register-staged fallbacks
     if (M >= 96 && N >= 96) {
         pl.bm = 128;
         pl.bn = (N % 160 == 0) ? 160 : 128;
@@ -483,7 +564,7 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
     int fbm = 0, fbn = 0, fpf = 0, fks = 0;
     if (f) sscanf(f, "%d,%d,%d,%d", &fbm, &fbn, &fpf, &fks);
     if (fbm && fbn) { pl.bm = fbm; pl.bn = fbn; }
-    if (fpf) pl.pf = fpf;
+    if (fpf) pl.pf = fpf == 9 ? 0 : fpf;  // 9 selects the LDS-DMA pipeline (pf 0)
     const int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
     const int nk = K / BK;
     if (batch == 1 && tiles < 200 && nk >= 8) {
@@ -519,9 +600,12 @@ int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipSt
         p.ksplit = pl.ksplit;
         p.ws = (float*)ws;
         const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
-        if (pl.bm == 128 && pl.bn == 160) e = pl.pf == 1 ? launch_bf16<CONV, 128, 160, 1>(p, gz, s) : launch_bf16<CONV, 128, 160, 2>(p, gz, s);
-        else if (pl.bm == 128 && pl.bn == 128) e = pl.pf == 1 ? launch_bf16<CONV, 128, 128, 1>(p, gz, s) : launch_bf16<CONV, 128, 128, 2>(p, gz, s);
-        else e = pl.pf == 1 ? launch_bf16<CONV, 64, 64, 1>(p, gz, s) : launch_bf16<CONV, 64, 64, 2>(p, gz, s);
+        if (pl.bm == 128 && pl.bn == 160)
+            e = pl.pf == 0 ? launch_bf16<CONV, 128, 160, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 128, 160, 1>(p, gz, s) : launch_bf16<CONV, 128, 160, 2>(p, gz, s);
+        else if (pl.bm == 128 && pl.bn == 128)
+            e = pl.pf == 0 ? launch_bf16<CONV, 128, 128, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 128, 128, 1>(p, gz, s) : launch_bf16<CONV, 128, 128, 2>(p, gz, s);
+        else
+            e = pl.pf == 0 ? launch_bf16<CONV, 64, 64, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 64, 64, 1>(p, gz, s) : launch_bf16<CONV, 64, 64, 2>(p, gz, s);
         if (e == hipSuccess && pl.ksplit > 1) {
             const int64_t total = (int64_t)p.M * ((p.N + 7) / 8);
             int64_t g = (total + 255) / 256;
@@ -549,7 +633,7 @@ extern "C" {
 
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype, int M, int N, int K, int64_t lda,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,
-                const float* rowbias, int rows_per_group, const void* residual, int64_t ldr, int64_t strideR, float alpha,
+                const float* rowbias, int rows_per_group, int64_t ldrb, const void* residual, int64_t ldr, int64_t strideR, float alpha,
                 int act, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_gemm_nt: bad dtype %d", dtype);
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
@@ -574,14 +658,14 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
         GMD_REQUIRE(dtype != GMD_BF16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_gemm_nt: operand slab larger than 4 GiB");
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     }
-    p.bias = bias; p.rowbias = rowbias; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+    p.bias = bias; p.rowbias = rowbias; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.ldrb = ldrb > 0 ? ldrb : N;
     p.residual = residual; p.ldr = ldr; p.sR = strideR; p.alpha = alpha; p.act = act;
     p.out_f32 = out_dtype == GMD_F32;
     return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
 }
 
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
-                int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, const void* residual,
+                int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_conv3x3: bad dtype %d", dtype);
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_conv3x3: out_dtype must be F32 or the input dtype");
@@ -608,7 +692,7 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
         GMD_REQUIRE(dtype != GMD_BF16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_conv3x3: tensor larger than 4 GiB");
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     }
-    p.bias = bias; p.rowbias = rowbias; p.rows_per_group = Hout * Wout;
+    p.bias = bias; p.rowbias = rowbias; p.rows_per_group = Hout * Wout; p.ldrb = ldrb > 0 ? ldrb : Cout;
     p.residual = residual; p.ldr = Cout; p.alpha = 1.0f; p.act = GMD_ACT_NONE;
     p.out_f32 = out_dtype == GMD_F32;
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.upsample = upsample; p.pad_lo = pad_lo;

@@ -13,8 +13,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmd_hip.so")
-ABI_VERSION = 1
+LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
+ABI_VERSION = 2
 
 GMD_F32, GMD_BF16 = 0, 1
 ACT_NONE, ACT_SILU = 0, 1
@@ -36,8 +36,8 @@ SIGNATURES = {
     "gmd_cfg_std_ratio": [P, I, L, F, P, P],
     "gmd_pack_unet_input": [P, I, P, I, I, L, I, P, I, I, P],
     "gmd_unpack_nchw": [P, I, L, I, I, L, P, P],
-    "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, P, L, L, F, I, P, L, P],
-    "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, P, P, L, P],
+    "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, L, P],
+    "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, L, P, P, L, P],
     "gmd_attention": [P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, P],
     "gmd_softmax_rows": [P, L, P, I, L, L, I, F, P],
     "gmd_groupnorm_nsplit": [L],

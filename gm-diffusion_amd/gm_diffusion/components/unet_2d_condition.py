@@ -323,9 +323,13 @@ class UNet2DConditionModel(_HipModule):
         w["te1"] = self._lin("time_embedding.linear_1")
         w["te2"] = self._lin("time_embedding.linear_2")
 
+        te_w, te_b = [], []
+
         def resnet(k):
-            r = dict(n1=self._norm(k + ".norm1"), c1=self._conv3(k + ".conv1"), te=self._lin(k + ".time_emb_proj"),
-                     n2=self._norm(k + ".norm2"), c2=self._conv3(k + ".conv2"))
+            r = dict(n1=self._norm(k + ".norm1"), c1=self._conv3(k + ".conv1"), n2=self._norm(k + ".norm2"), c2=self._conv3(k + ".conv2"))
+            r["te_off"] = sum(t.shape[0] for t in te_w)  # column offset into the fused time-embedding projection
+            te_w.append(self._raw[k + ".time_emb_proj.weight"])
+            te_b.append(self._raw[k + ".time_emb_proj.bias"])
             if k + ".conv_shortcut.weight" in self._raw:
                 r["sc"] = self._lin(k + ".conv_shortcut")
             return r
@@ -368,6 +372,8 @@ class UNet2DConditionModel(_HipModule):
             w["up"].append(e)
         w["norm_out"] = self._norm("conv_norm_out")
         w["conv_out"] = self._conv3("conv_out")
+        # all ResnetBlock2D.time_emb_proj layers as ONE [sum(Cout), 1280] GEMM per forward
+        w["te_all"] = (self._act(torch.cat(te_w, 0)), self._f32(torch.cat(te_b, 0)))
         self._kv_cache = {}
         self._t_dev = torch.zeros(1, dtype=torch.float32, device=self._device)
         return w
@@ -378,8 +384,7 @@ class UNet2DConditionModel(_HipModule):
     def _resnet(self, r, x, B, H, W, temb, eps):
         G = self.config.norm_num_groups
         h = ops.groupnorm(x, B, G, r["n1"][0], r["n1"][1], eps, silu=True)
-        tp = ops.gemm_nt(temb, r["te"][0], bias=r["te"][1], out_dtype=torch.float32)
-        h, _, _ = ops.conv3x3(h, r["c1"][0], B, H, W, bias=r["c1"][1], rowbias=tp)
+        h, _, _ = ops.conv3x3(h, r["c1"][0], B, H, W, bias=r["c1"][1], rowbias=(temb, r["te_off"]))
         h = ops.groupnorm(h, B, G, r["n2"][0], r["n2"][1], eps, silu=True)
         if "sc" in r:
             cin = x.shape[-1]
@@ -464,6 +469,7 @@ class UNet2DConditionModel(_HipModule):
         te = ops.timestep_embedding(self._t_dev, B, c.block_out_channels[0], self._dtype, c.flip_sin_to_cos, c.freq_shift)
         te = ops.gemm_nt(te, w["te1"][0], bias=w["te1"][1], act=ops.ACT_SILU)
         temb = ops.gemm_nt(te, w["te2"][0], bias=w["te2"][1], act=ops.ACT_SILU)  # = silu(temb): the only use of temb
+        temb = ops.gemm_nt(temb, w["te_all"][0], bias=w["te_all"][1], out_dtype=torch.float32)  # [B, sum(Cout)] f32
         x, _, _ = ops.conv3x3(x, w["conv_in"][0], B, H, W, bias=w["conv_in"][1])
         skips = [(x, H, W)]
         for blk in w["down"]:

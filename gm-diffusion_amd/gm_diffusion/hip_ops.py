@@ -57,11 +57,28 @@ WORKSPACE_BYTES = 96 << 20
 
 
 def _workspace(device):
-    """Persistent float32 scratch (per device) that lets under-filled GEMM/conv launches split K."""
-    ws = _WS.get(device)
+    """Persistent float32 scratch, one per (device, stream) so that concurrent streams never share it; it lets
+    under-filled GEMM/conv launches split K."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
-        ws = _WS[device] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        ws = _WS[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return ws
+
+
+def _rowbias(rb):
+    """rowbias may be a float32 tensor [G, N] or a (tensor [G, ld], column offset) pair selecting N columns of a wider
+    matrix (all ResnetBlock2D time-embedding projections of a UNet are produced by ONE GEMM)."""
+    if rb is None:
+        return None, 0
+    if isinstance(rb, tuple):
+        t, col = rb
+        _dev(t)
+        _f32(t, "rowbias")
+        return t.data_ptr() + col * 4, t.shape[-1]
+    _dev(rb)
+    _f32(rb, "rowbias")
+    return rb.data_ptr(), rb.shape[-1]
 
 
 def _f32(t, name):
@@ -78,7 +95,8 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     """``act(alpha * a @ w.T + bias + rowbias[m // rows_per_group] + residual)``.
 
     a: [M, K] or [batch, M, K]; w: [N, K] or [batch, N, K] (a 2-D operand is shared by the batch)."""
-    _dev(a, w, bias, rowbias, residual, out)
+    _dev(a, w, bias, residual, out)
+    rb_ptr, rb_ld = _rowbias(rowbias)
     if a.dtype != w.dtype:
         raise HipExtensionError(f"gemm_nt: dtype mismatch {a.dtype} vs {w.dtype}")
     dt = dtype_code(a.dtype)
@@ -108,7 +126,7 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     tm = profiling.active()
     t0 = tm.begin() if tm else None
     check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, dtype_code(out_dtype), M, N, K, K, K, ldc, batch, sA, sW, sC,
-                            _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")), rows_per_group,
+                            _ptr(_f32(bias, "bias")), rb_ptr, rows_per_group, rb_ld,
                             _ptr(residual), N, sR, float(alpha), act, _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_gemm_nt")
     if tm:
         es = a.element_size()
@@ -118,7 +136,8 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
 
 def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, upsample=False, pad_mode=0, out_dtype=None):
     """x: [B, H*W, Cin]; w: [Cout, 9*Cin] (tap-major); returns ([B, Hout*Wout, Cout], Hout, Wout)."""
-    _dev(x, w, bias, rowbias, residual)
+    _dev(x, w, bias, residual)
+    rb_ptr, rb_ld = _rowbias(rowbias)
     cin, cout = x.shape[-1], w.shape[0]
     if x.numel() != B * H * W * cin or w.shape[1] != 9 * cin or x.dtype != w.dtype:
         raise HipExtensionError(f"conv3x3: shape/dtype mismatch x={tuple(x.shape)} w={tuple(w.shape)} B,H,W={B},{H},{W}")
@@ -132,13 +151,13 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     y = torch.empty((B, ho * wo, cout), dtype=out_dtype, device=x.device)
     if residual is not None and (residual.numel() != y.numel() or residual.dtype != x.dtype):
         raise HipExtensionError("conv3x3: residual shape/dtype mismatch")
-    if rowbias is not None and rowbias.numel() != B * cout:
-        raise HipExtensionError("conv3x3: rowbias must be [B, Cout]")
+    if rowbias is not None and (rowbias[0] if isinstance(rowbias, tuple) else rowbias).shape[0] != B:
+        raise HipExtensionError("conv3x3: rowbias must have one row per sample")
     ws = _workspace(x.device)
     tm = profiling.active()
     t0 = tm.begin() if tm else None
     check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, H, W, cin, cout,
-                            stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), _ptr(_f32(rowbias, "rowbias")),
+                            stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), rb_ptr, rb_ld,
                             _ptr(residual), _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_conv3x3")
     if tm:
         tm.end("conv3x3", 2.0 * B * ho * wo * cout * 9 * cin, x.numel() * x.element_size() + w.numel() * w.element_size()
@@ -391,5 +410,5 @@ def gemm_raw(a_ptr, w_ptr, c_ptr, dtype, out_dtype, M, N, K, lda, ldw, ldc, batc
     a_ptr/w_ptr/c_ptr are integer device addresses; the caller keeps the owning tensors alive."""
     _dev(bias)
     check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, dtype_code(dtype), dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
-                            sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, None, 0, 0, float(alpha), act, None, 0, _stream()),
+                            sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, 0, None, 0, 0, float(alpha), act, None, 0, _stream()),
           "gmd_gemm_nt")

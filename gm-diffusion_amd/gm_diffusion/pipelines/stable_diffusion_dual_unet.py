@@ -36,10 +36,19 @@ __all__ = ["StableDiffusionDualUNetPipeline", "rescale_noise_cfg", "retrieve_tim
 
 
 class StableDiffusionDualUNetPipeline(_GMPipelineBase):
+    overlap_streams = True  # run the GM UNet on a second HIP stream, overlapped with the next SDR step
+
     def __init__(self, vae, text_encoder, tokenizer, unet, gm_unet, scheduler, safety_checker, feature_extractor,
                  image_encoder=None, requires_safety_checker: bool = True):
         self._init_common(vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor, image_encoder,
                           requires_safety_checker, gm_unet=gm_unet)
+        self._gm_streams = {}
+
+    def _gm_stream(self, device):
+        s = self._gm_streams.get(device)
+        if s is None:
+            s = self._gm_streams[device] = torch.cuda.Stream(device=device)
+        return s
 
     @torch.no_grad()
     def __call__(
@@ -116,6 +125,12 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
             ctx = self.unet.prepare_context(prompt_embeds)
             gm_ctx = self.gm_unet.prepare_context(gm_prompt_embeds)
             h, w = latents.shape[-2:]
+            # The GM UNet of step i needs only x0_i; the SDR UNet of step i+1 needs only latents_{i+1}: the two are
+            # independent, so the GM stream runs on its own HIP stream one step behind the SDR stream and their
+            # kernels overlap (the batch-B GM kernels alone cannot fill 256 CUs).
+            sdr_stream = torch.cuda.current_stream(latents.device)
+            gm_stream = self._gm_stream(latents.device) if self.overlap_streams else sdr_stream
+            gm_stream.wait_stream(sdr_stream)
 
         with self.progress_bar(total=num_inference_steps) as progress_bar:
             for i, t in enumerate(timesteps):
@@ -128,10 +143,13 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                     pre_step = latents
                     latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, t, pre_step, do_cfg, self.guidance_scale,
                                                                    self.guidance_rescale if do_cfg else 0.0, want_x0=True)
-                    gx = self.gm_unet.pack_input((x0_latent, gm_latents), dup=1)
-                    self.gm_unet.set_timestep(t)
-                    gm_noise_pred = self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
-                    gm_latents = self.gm_scheduler.step(gm_noise_pred, t, gm_latents, return_dict=False)[0]
+                    with torch.cuda.stream(gm_stream):
+                        gm_stream.wait_stream(sdr_stream)  # x0_i is ready
+                        x0_latent.record_stream(gm_stream)
+                        gx = self.gm_unet.pack_input((x0_latent, gm_latents), dup=1)
+                        self.gm_unet.set_timestep(t)
+                        gm_noise_pred = self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
+                        gm_latents = self.gm_scheduler.step(gm_noise_pred, t, gm_latents, return_dict=False)[0]
                 else:
                     latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
                     latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
@@ -162,6 +180,9 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                         step_idx = i // getattr(self.scheduler, "order", 1)
                         callback(step_idx, t, latents)
 
+        if fused:
+            sdr_stream.wait_stream(gm_stream)  # join: the caller sees both results on its own stream
+            gm_latents.record_stream(sdr_stream)
         if output_type == "latent":
             return (latents, gm_latents)
         sf = self.vae.config.scaling_factor

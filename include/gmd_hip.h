@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 1
+#define GMD_ABI_VERSION 2
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -136,7 +136,7 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
 
 /* C[b] = act(alpha * A[b] @ W[b]^T + bias + rowbias + residual).
  * A: [M,K] ld lda; W: [N,K] ld ldw (both K-contiguous); C: [M,N] ld ldc, out_dtype F32 or `dtype`.
- * bias: float32 [N] or NULL.  rowbias: float32 [ceil(M/rows_per_group), N] or NULL, added to rows
+ * bias: float32 [N] or NULL.  rowbias: float32 [ceil(M/rows_per_group), ldrb] (ldrb >= N; 0 means N) or NULL, added to rows
  * of group m/rows_per_group (ResnetBlock2D time-embedding add).  residual: `dtype` [M,N] ld ldr or NULL.
  * Requirements: K % 64 == 0 (BF16) / K % 4 == 0 (F32); lda, ldw multiples of 8 (BF16) / 4 (F32) elements;
  * base pointers 16-byte aligned.  nn.Linear / conv1x1 / attention score products.
@@ -145,7 +145,7 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 int M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
                 int batch, int64_t strideA, int64_t strideW, int64_t strideC,
-                const float* bias, const float* rowbias, int rows_per_group,
+                const float* bias, const float* rowbias, int rows_per_group, int64_t ldrb,
                 const void* residual, int64_t ldr, int64_t strideR,
                 float alpha, int act, void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
 
@@ -154,10 +154,10 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
  * stride 1 or 2 (Downsample2D: Hout = (Hin+2-3)/2+1); upsample=1 fuses nearest-2x
  * (Upsample2D: conv over the virtual 2Hin x 2Win image).  pad_mode 0: symmetric padding 1;
  * pad_mode 1: pad (0,1,0,1) then stride 2 (VAE encoder Downsample2D(padding=0)).
- * Epilogue as gmd_gemm_nt (rowbias is [B,Cout]).  Cin % 64 == 0 (BF16) / % 16 (F32). */
+ * Epilogue as gmd_gemm_nt (rowbias is [B, ldrb], one row per sample).  Cin % 64 == 0 (BF16) / % 16 (F32). */
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype,
                 int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode,
-                const float* bias, const float* rowbias, const void* residual,
+                const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
 
 /* Flash-style attention, bf16 MFMA: O = softmax(scale * Q K^T) V per (batch, head).

@@ -1,0 +1,17 @@
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gm-diffusion_amd"))
+import torch
+from gm_diffusion import hip_ops as ops
+M, N, K = [int(v) for v in sys.argv[1:4]]
+mode = sys.argv[4] if len(sys.argv) > 4 else "bias"
+g = torch.Generator().manual_seed(0)
+a = torch.randn(M, K, generator=g).bfloat16().cuda(); w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda(); b = torch.randn(N, generator=g).cuda()
+kw = dict(bias=b) if mode == "bias" else {}
+if mode == "f32": kw = dict(out_dtype=torch.float32)
+for _ in range(3): ops.gemm_nt(a, w, **kw)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): ops.gemm_nt(a, w, **kw)
+e1.record(); torch.cuda.synchronize()
+print("GEMM", os.environ.get("GMD_LIB_OVERRIDE", "prod")[-8:], M, N, K, mode, "%.1f us" % (e0.elapsed_time(e1) / 20 * 1e3))
