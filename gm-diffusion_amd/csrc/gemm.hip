@@ -565,13 +565,17 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
     if (f) sscanf(f, "%d,%d,%d,%d", &fbm, &fbn, &fpf, &fks);
     if (fbm && fbn) { pl.bm = fbm; pl.bn = fbn; }
     if (fpf) pl.pf = fpf == 9 ? 0 : fpf;  // 9 selects the LDS-DMA pipeline (pf 0)
-    const int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
+    int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
     const int nk = K / BK;
-    if (batch == 1 && tiles < 200 && nk >= 8) {
+    if (batch == 1 && tiles < 160 && nk >= 24) {  // K >= 1536: the slab reduction (a second launch) must pay for itself
         int ks = (int)((384 + tiles - 1) / tiles);
-        if (ks > nk / 4) ks = nk / 4;
+        if (ks > nk / 8) ks = nk / 8;  // at least 8 K steps (512 channels) per slice
         if (ks > 16) ks = 16;
         if (ks > 1 && (int64_t)ks * M * N * (int64_t)sizeof(float) <= ws_bytes) pl.ksplit = ks;
+    }
+    if (pl.ksplit == 1 && tiles < 256 && pl.bm == 128 && !(fbm && fbn)) {  // cannot fill the chip: 4-5x more, smaller tiles
+        pl.bm = 64;
+        pl.bn = 64;
     }
     if (fks) pl.ksplit = ((int64_t)fks * M * N * (int64_t)sizeof(float) <= ws_bytes && batch == 1) ? fks : 1;
     return pl;

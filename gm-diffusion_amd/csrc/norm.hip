@@ -71,24 +71,32 @@ __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const T* __restric
     }
 }
 
-// grid B: fold the splits (fixed order, double), then per-channel affine
+// grid B: fold the splits (8 lanes per group, each a fixed strided subset, then a fixed-order shuffle tree:
+// deterministic), then per-channel affine
 __global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __restrict__ ws, int nsplit, int64_t HW, int C,
                                                                int G, float eps, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ ss) {
     __shared__ float s_mean[64], s_rstd[64];
     const int b = blockIdx.x, cpg = C / G;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
+        const int g = g0 + (int)threadIdx.x / 8, sub = threadIdx.x & 7;
         double s = 0.0, s2 = 0.0;
-        for (int k = 0; k < nsplit; ++k) {
-            const float* o = ws + (((int64_t)b * nsplit + k) * G + g) * 2;
-            s += o[0]; s2 += o[1];
+        if (g < G) {
+            for (int k = sub; k < nsplit; k += 8) {
+                const float2 o = *reinterpret_cast<const float2*>(ws + (((int64_t)b * nsplit + k) * G + g) * 2);
+                s += o.x; s2 += o.y;
+            }
         }
-        const double n = (double)HW * cpg;
-        const double mean = s / n;
-        double var = s2 / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean[g] = (float)mean;
-        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (g < G && sub == 0) {
+            const double n = (double)HW * cpg;
+            const double mean = s / n;
+            double var = s2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_mean[g] = (float)mean;
+            s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
