@@ -1,0 +1,81 @@
+"""CPU: the numpy oracle of the HDR ops against golden vectors produced by the REFERENCE's own
+tone_mapping.py / augmentations.py (tests/golden/hdr_ops_reference.npz, oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import hdr_ops as H
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "hdr_ops_reference.npz"))
+
+
+def _close(a, b, ulps=2, floor=2.4e-7):
+    """|a-b| <= ulps * ulp(max(|a|,|b|)) + floor.  The floor (2 ulp of 1.0) covers sums with cancellation
+    (gamut matrix, log ratio) whose ABSOLUTE error is one rounding of an O(1) intermediate."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert a.shape == b.shape
+    tol = ulps * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64) + floor
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    assert np.all(d <= tol), float(d.max())
+
+
+def test_denorm_and_linear_ops_exact(g):
+    assert np.array_equal(H.denorm_clamp(g["sdr_dec"]), g["sdr"])
+    assert np.array_equal(H.denorm_clamp(g["gm_dec"]), g["gm"])
+    for q in (9, 49, 99):
+        hdr = g[f"apply_gm_to_sdr_q{q}"]
+        assert np.array_equal(H.linear_scale_tmo(hdr, q), g[f"linear_scale_tmo_q{q}"])
+        assert np.array_equal(H.hard_clip_tmo(hdr, q), g[f"hard_clip_tmo_q{q}"])
+
+
+@pytest.mark.parametrize("q", [9, 49, 99])
+def test_eq1_and_tmos_within_ulps(g, q):
+    # float32 pow/log1p differ by <= 1-2 ulp between numpy and the torch the reference ran on
+    _close(H.apply_gm_to_sdr(g["gm"], g["sdr"], qmax=q), g[f"apply_gm_to_sdr_q{q}"], ulps=4)
+    _close(H.fix_mulog_tmo(g[f"apply_gm_to_sdr_q{q}"], q), g[f"fix_mulog_tmo_q{q}"])
+    _close(H.gamut_compress(g[f"fix_mulog_tmo_q{q}"]), g[f"stage1_chain_q{q}"], ulps=4)
+
+
+def test_defaults_and_other_tmos(g):
+    _close(H.apply_gm_to_sdr(g["gm"], g["sdr"]), g["apply_gm_to_sdr_default"], ulps=4)
+    _close(H.tmo_cuda(g["apply_gm_to_sdr_q9"]), g["tmo_cuda"])
+    _close(H.gamut_compress(g["sdr"]), g["gamut_compress"], ulps=4)
+    _close(H.gamut_compress(g["apply_gm_to_sdr_q9"]), g["gamut_compress_hdr"], ulps=4)
+    _close(H.mulog_tmo(g["apply_gm_to_sdr_q49"], 49, float(g["random_tmo_mu"])), g["random_tmo_cuda_q49"])
+    _close(H.apply_gm_to_sdr(np.clip(g["edge"][::-1], 0, 1), g["edge"], qmax=99), g["edge_apply_q99"], ulps=4)
+
+
+def test_uint16_discretiser_bit_exact(g):
+    assert np.array_equal(H.discretize_to_uint16(g["u16_in"]), g["discretize_to_uint16"])
+    codes = H.quantize_u16_codes(g["u16_in"])
+    assert codes.dtype == np.uint16
+    assert np.array_equal((codes.astype(np.float32) / np.float32(65535)), g["discretize_to_uint16"])
+    # round-half-to-even on exact .5 codes
+    x = (np.array([0.5, 1.5, 2.5, 3.5], np.float32) / np.float32(65535)).astype(np.float32)
+    got = H.quantize_u16_codes(x)
+    assert set(got.tolist()) <= {0, 1, 2, 3, 4}
+
+
+def test_uint8_truncation_and_variants():
+    x = np.array([0.0, 0.999, 1.0, 254.9 / 255, 0.5], np.float32)
+    assert H.quantize_u8_trunc(x).tolist() == [0, 254, 255, 254, 127]
+    sdr = np.random.default_rng(0).random((1, 4, 5, 3), dtype=np.float32)
+    gm = np.random.default_rng(1).random((1, 4, 5, 3), dtype=np.float32)
+    clamped = H.apply_gm_to_sdr(gm, sdr, qmax=9, clamp=True)
+    raw = H.apply_gm_to_sdr(gm, sdr, qmax=9, clamp=False)
+    assert np.array_equal(clamped, np.clip(raw, 0, 10))
+    assert raw.min() >= -1 / 64
+
+
+def test_tail_composition_shapes():
+    rng = np.random.default_rng(2)
+    a = (rng.random((2, 3, 6, 8), dtype=np.float32) * 2.4 - 1.2).astype(np.float32)
+    b = (rng.random((2, 3, 6, 8), dtype=np.float32) * 2.4 - 1.2).astype(np.float32)
+    t = H.hdr_tail(a, b, qmax=99)
+    assert t["hdr"].shape == (2, 6, 8, 3) and t["sdr_u8"].dtype == np.uint8
+    assert np.array_equal(t["hdr_file"], (t["hdr"] / np.float32(100)).astype(np.float32))
+    assert np.array_equal(H.save_hdr_scale(t["hdr"], 99), t["hdr_file"][..., [2, 1, 0]])
