@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--unet", default="sd15", choices=["sd15", "tiny"], help="tiny = structural smoke config (not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="run the GM UNet on a second HIP stream (A/B; measured no gain)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (a 1-GPU box owns 16 cores)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     return ap.parse_args()
 
@@ -56,7 +58,7 @@ def cpu_baseline(res, steps, cores_hint=None):
     (the 8-channel UNet differs only in conv_in: timed as the 4-channel one)."""
     from oracle import fixtures
 
-    cores = cores_hint or os.cpu_count() or 1
+    cores = min(cores_hint or 16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     h = res // 8
     with torch.no_grad():
@@ -115,6 +117,7 @@ def main():
                                            scheduler=sched, safety_checker=None, feature_extractor=None,
                                            requires_safety_checker=False)
     pipe.set_progress_bar_config(disable=True)
+    pipe.overlap_streams = a.overlap
 
     B = a.batch
     total = B * world
@@ -146,9 +149,11 @@ def main():
     for _ in range(a.warmup):
         out = step()
     fence()
+    # HIP events in the timed region bracket ONLY the dominant kernel (conv3x3: ~5.4k of ~45k launches per step), so the
+    # instrumentation does not perturb the headline; the full per-kernel breakdown comes from one extra untimed step.
     timer = None
     if not a.no_kernel_timing and rank == 0:
-        timer = profiling.KernelTimer()
+        timer = profiling.KernelTimer(kinds={"conv3x3"})
         profiling.set_timer(timer)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -156,6 +161,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     profiling.set_timer(None)
+    full_timer = None
+    if not a.no_kernel_timing and rank == 0:
+        full_timer = profiling.KernelTimer()
+        profiling.set_timer(full_timer)
+        step()
+        torch.cuda.synchronize()
+        profiling.set_timer(None)
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -166,14 +180,16 @@ def main():
         roof = None
         kernels = {}
         if timer is not None:
-            summ = timer.summary()
+            full = full_timer.summary()  # one extra, untimed, fully instrumented step
             kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_us": round(v["avg_us"], 2),
-                           "tflops": round(v["tflops"], 2)} for k, v in summ.items()}
-            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            roof = {"kernel": "gmd_" + dom[0], "bound": "mfma", "achieved": round(dom[1]["tflops"], 2), "peak": BF16_DENSE_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
-                    "launches": dom[1]["launches"], "avg_launch_us": round(dom[1]["avg_us"], 2),
-                    "share_of_kernel_time": round(dom[1]["ms"] / sum(v["ms"] for v in summ.values()), 3)}
+                           "tflops": round(v["tflops"], 2)} for k, v in full.items()}
+            dom = timer.summary()["conv3x3"]  # measured INSIDE the timed region
+            roof = {"kernel": "gmd_conv3x3 (gemm_bf16_kernel<CONV=true>: implicit-GEMM conv3x3, 49.6% of UNet / 96.8% of VAE FLOPs)",
+                    "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": BF16_DENSE_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": dom["launches"], "avg_launch_us": round(dom["avg_us"], 2),
+                    "flops_per_launch_avg": round(dom["flops"] / dom["launches"]),
+                    "share_of_instrumented_kernel_time": round(full["conv3x3"]["ms"] / sum(v["ms"] for v in full.values()), 3)}
         res = {
             "metric": "HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet", "value": round(total * a.steps / elapsed, 4),
             "unit": "HDR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -188,7 +204,7 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(a.res, a.inference_steps)
+                res["cpu_baseline"] = cpu_baseline(a.res, a.inference_steps, a.cpu_threads)
             except Exception as e:  # pragma: no cover
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))

@@ -124,6 +124,7 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
         raise HipExtensionError("gemm_nt: bias must have N elements")
     ws = _workspace(a.device) if batch == 1 else None
     tm = profiling.active()
+    tm = tm if tm is not None and tm.wants("gemm_nt") else None
     t0 = tm.begin() if tm else None
     check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, dtype_code(out_dtype), M, N, K, K, K, ldc, batch, sA, sW, sC,
                             _ptr(_f32(bias, "bias")), rb_ptr, rows_per_group, rb_ld,
@@ -155,6 +156,7 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
         raise HipExtensionError("conv3x3: rowbias must have one row per sample")
     ws = _workspace(x.device)
     tm = profiling.active()
+    tm = tm if tm is not None and tm.wants("conv3x3") else None
     t0 = tm.begin() if tm else None
     check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, H, W, cin, cout,
                             stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), rb_ptr, rb_ld,
@@ -177,6 +179,7 @@ def attention(q, k, vt, heads, nk, scale, k_col=0):
         raise HipExtensionError("attention: operand shapes inconsistent")
     o = torch.empty((B, nq, hd), dtype=q.dtype, device=q.device)
     tm = profiling.active()
+    tm = tm if tm is not None and tm.wants("attention") else None
     t0 = tm.begin() if tm else None
     check(lib().gmd_attention(_ptr(q), _ptr(k) + k_col * k.element_size(), _ptr(vt), _ptr(o), dtype_code(q.dtype), B, heads, d,
                               nq, nk, ldq, ldk, vt.shape[2], hd, nq * ldq, k.shape[1] * ldk, hd * vt.shape[2], nq * hd,

@@ -36,7 +36,9 @@ __all__ = ["StableDiffusionDualUNetPipeline", "rescale_noise_cfg", "retrieve_tim
 
 
 class StableDiffusionDualUNetPipeline(_GMPipelineBase):
-    overlap_streams = True  # run the GM UNet on a second HIP stream, overlapped with the next SDR step
+    # Optional: run the GM UNet on a second HIP stream one step behind the SDR stream.  Measured on MI355X (bench.py
+    # --no-overlap A/B): 2.81 vs 2.85 images/s -- the kernels of one stream already occupy the chip, so it is off by default.
+    overlap_streams = False
 
     def __init__(self, vae, text_encoder, tokenizer, unet, gm_unet, scheduler, safety_checker, feature_extractor,
                  image_encoder=None, requires_safety_checker: bool = True):

@@ -11,8 +11,15 @@ import torch
 
 
 class KernelTimer:
-    def __init__(self):
+    """kinds=None times every instrumented launch; a set of kind names (e.g. {"conv3x3"}) times only those, which keeps
+    the event overhead inside a timed region negligible."""
+
+    def __init__(self, kinds=None):
         self.records = []  # (kind, flops, bytes, start_event, end_event)
+        self.kinds = set(kinds) if kinds else None
+
+    def wants(self, kind):
+        return self.kinds is None or kind in self.kinds
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
