@@ -162,6 +162,86 @@ constexpr int BK = 64;  // bf16 elements per K step = 128 bytes = 8 chunks of 16
 // 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups of a 16x16x32 fragment conflict-free
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// Epilogue straight from registers.  The MFMA operands are swapped (W fragment as A, activation fragment as B), so
+// by the C/D layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds FOUR CONSECUTIVE output columns n of ONE
+// row m: bias/row-bias/residual/activation are applied in registers and each lane stores 8 bytes (bf16) or 16 bytes
+// (fp32 / split-K partials) -- no LDS round trip, no barrier.  mw/nw: first row/column of this wave's tile.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (&acc)[TM][TN], int mw, int nw, int frow, int fq,
+                                              int z, int ks) {
+    const bool vec_c = (p.ldc % 4 == 0) && (p.sC % 4 == 0);
+    const bool vec_r = p.residual != nullptr && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
+    const bool vec_n = (p.N % 4 == 0);
+    const bool vec_rb = vec_n && (p.ldrb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0);
+    float bz[TN][4];  // per-column bias of this lane's TN column groups, loaded once (16-byte loads)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 16 + fq * 4;
+        bz[j][0] = bz[j][1] = bz[j][2] = bz[j][3] = 0.f;
+        if (p.bias && p.ksplit <= 1 && n < p.N) {
+            if (n + 4 <= p.N && vec_n) {
+                const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
+                bz[j][0] = t.x; bz[j][1] = t.y; bz[j][2] = t.z; bz[j][3] = t.w;
+            } else {
+                for (int e = 0; e < 4; ++e) if (n + e < p.N) bz[j][e] = p.bias[n + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mw + i * 16 + frow;
+        if (m >= p.M) continue;
+        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nw + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            const int nvalid = p.N - n < 4 ? p.N - n : 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.ksplit > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
+                float* o = p.ws + ((int64_t)ks * p.M + m) * p.N + n;
+                if (nvalid == 4 && vec_n) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+                continue;
+            }
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) {
+                const bf16_t* res = (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n;
+                if (nvalid == 4 && vec_r) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(res);
+                    rv[0] = __uint_as_float(w.x << 16); rv[1] = __uint_as_float(w.x & 0xffff0000u);
+                    rv[2] = __uint_as_float(w.y << 16); rv[3] = __uint_as_float(w.y & 0xffff0000u);
+                } else {
+                    for (int e = 0; e < nvalid; ++e) rv[e] = bf16_to_f32(res[e]);
+                }
+            }
+            if (rb) {
+                if (nvalid == 4 && vec_rb) {
+                    const float4 t = *reinterpret_cast<const float4*>(rb + n);
+                    rv[0] += t.x; rv[1] += t.y; rv[2] += t.z; rv[3] += t.w;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) rv[e] += rb[n + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[j][e] + rv[e], p.act);
+            const int64_t coff = (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+            if (p.out_f32) {
+                float* o = (float*)p.C + coff;
+                if (nvalid == 4 && vec_c) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+            } else {
+                bf16_t* o = (bf16_t*)p.C + coff;
+                if (nvalid == 4 && vec_c) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                else
+                    for (int e = 0; e < nvalid; ++e) o[e] = f32_to_bf16(v[e]);
+            }
+        }
+    }
+}
+
 template <int V> struct IntC { static constexpr int value = V; };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -401,82 +481,176 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         }
     }
 
-    // ---- epilogue straight from registers.  The MFMA operands are swapped (W fragment as A, activation fragment
-    // as B), so by the C/D layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds FOUR CONSECUTIVE output
-    // columns n of ONE row m: bias/residual/activation are applied in registers and each lane stores 8 bytes
-    // (bf16) or 16 bytes (fp32 / split-K partials) -- no LDS round trip, no barrier.
-    const bool vec_c = (p.ldc % 4 == 0) && (p.sC % 4 == 0);
-    const bool vec_r = p.residual != nullptr && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
-    const bool vec_n = (p.N % 4 == 0);
-    const bool vec_rb = vec_n && (p.ldrb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0);
-    // per-column bias of this lane's TN column groups, loaded once (16-byte loads) ahead of the row loop
-    float bz[TN][4];
+    epilogue_regs<TM, TN>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 2), frow, fq, z, ks);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, ring form: WM x WN waves (wave tile 64 x 16*TN), NST-stage LDS ring filled by LDS-DMA with
+// COUNTED waits -- the DMAs of the next NST-2 tiles stay in flight across the per-tile barrier, so the ~1 us
+// DMA latency is covered by NST-1 tiles of MFMA work instead of one.
+//   iteration kt:  s_waitcnt vmcnt(groups still allowed in flight)   tile kt of THIS wave has landed
+//                  barrier                                           ... of every wave; stage (kt-1)%NST is free
+//                  issue DMA of tile kt+NST-1 into stage (kt-1)%NST
+//                  MFMAs on stage kt%NST
+// ------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool CONV, int WM, int WN, int TN, int NST>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(const GemmParams p) {
+    constexpr int NWAVES = WM * WN, TM = 4;
+    constexpr int BM = WM * 64, BN = WN * TN * 16;
+    constexpr int RPP = NWAVES * 8;                 // tile rows written per staging pass (8 rows per wave instruction)
+    constexpr int NA = BM / RPP;                    // A staging slots per thread
+    constexpr int NW = (BN + RPP - 1) / RPP;        // W staging slots per thread (the last may be invalid for some waves)
+    constexpr bool W_RAGGED = (BN % RPP) != 0;
+    constexpr int D = NST - 1;                      // prefetch distance in tiles
+    static_assert(BM % RPP == 0 && BN % 8 == 0 && NST >= 2 && NST <= 4, "bad ring geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kStage = (BM + BN) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WN, wc = wid % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int z = p.ksplit > 1 ? 0 : blockIdx.z;
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    const int srow = tid >> 3;                                    // 0 .. RPP-1
+    const int chunk = (tid & 7) ^ ((srow >> 1) & 7);              // swizzled SOURCE chunk (RPP is a multiple of 16)
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+
+    unsigned aoff[NA], woff[NW];
+    int pb[NA], py[NA], px[NA];
+    bool pv[NA];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * (BN / 2) + j * 16 + fq * 4;
-        bz[j][0] = bz[j][1] = bz[j][2] = bz[j][3] = 0.f;
-        if (p.bias && p.ksplit <= 1 && n < p.N) {
-            if (n + 4 <= p.N && vec_n) {
-                const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
-                bz[j][0] = t.x; bz[j][1] = t.y; bz[j][2] = t.z; bz[j][3] = t.w;
-            } else {
-                for (int e = 0; e < 4; ++e) if (n + e < p.N) bz[j][e] = p.bias[n + e];
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + srow + RPP * i;
+        pv[i] = m < p.M;
+        pb[i] = py[i] = px[i] = 0;
+        if (CONV) {
+            if (pv[i]) {
+                const int hw = p.Hout * p.Wout;
+                pb[i] = m / hw;
+                const int rem = m - pb[i] * hw;
+                py[i] = rem / p.Wout;
+                px[i] = rem - py[i] * p.Wout;
             }
+            aoff[i] = kOOB;
+        } else {
+            aoff[i] = pv[i] ? (unsigned)m * (unsigned)p.lda * 2u + (unsigned)chunk * 16u : kOOB;
         }
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wr * (BM / 2) + i * 16 + frow;
-        if (m >= p.M) continue;
-        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
+    for (int i = 0; i < NW; ++i) {
+        const int rl = srow + RPP * i;  // row inside the W tile
+        const int n = n0 + rl;
+        woff[i] = (rl < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldw * 2u + (unsigned)chunk * 16u : kOOB;
+    }
+    // does this wave own a valid row group in the last (ragged) W pass?  wave-uniform
+    const bool w_last = !W_RAGGED || ((NW - 1) * RPP + wuni * 8 < BN);
+
+    f32x4 acc[TM][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * (BN / 2) + j * 16 + fq * 4;
-            if (n >= p.N) continue;
-            const int nvalid = p.N - n < 4 ? p.N - n : 4;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.ksplit > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_kernel
-                float* o = p.ws + ((int64_t)ks * p.M + m) * p.N + n;
-                if (nvalid == 4 && vec_n) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int e = 0; e < nvalid; ++e) o[e] = v[e];
-                continue;
-            }
-            float rv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.residual) {
-                const bf16_t* res = (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n;
-                if (nvalid == 4 && vec_r) {
-                    const uint2 w = *reinterpret_cast<const uint2*>(res);
-                    rv[0] = __uint_as_float(w.x << 16); rv[1] = __uint_as_float(w.x & 0xffff0000u);
-                    rv[2] = __uint_as_float(w.y << 16); rv[3] = __uint_as_float(w.y & 0xffff0000u);
-                } else {
-                    for (int e = 0; e < nvalid; ++e) rv[e] = bf16_to_f32(res[e]);
-                }
-            }
-            if (rb) {
-                if (nvalid == 4 && vec_rb) {
-                    const float4 t = *reinterpret_cast<const float4*>(rb + n);
-                    rv[0] += t.x; rv[1] += t.y; rv[2] += t.z; rv[3] += t.w;
-                } else {
-                    for (int e = 0; e < nvalid; ++e) rv[e] += rb[n + e];
-                }
-            }
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[j][e] + rv[e], p.act);
-            const int64_t coff = (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
-            if (p.out_f32) {
-                float* o = (float*)p.C + coff;
-                if (nvalid == 4 && vec_c) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int e = 0; e < nvalid; ++e) o[e] = v[e];
-            } else {
-                bf16_t* o = (bf16_t*)p.C + coff;
-                if (nvalid == 4 && vec_c) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                else
-                    for (int e = 0; e < nvalid; ++e) o[e] = f32_to_bf16(v[e]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = p.K / BK;
+    const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * per;
+    const int nk = (kt_begin + per <= nk_total ? per : nk_total - kt_begin);
+    int tap = 0, c0 = 0;
+    bool newtap = true;
+    if (CONV) {
+        const int kb = kt_begin * BK;
+        tap = kb / p.Cin;
+        c0 = kb - tap * p.Cin;
+    }
+
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    u32x4 dA, dW;
+    {
+        const uint64_t ba = (uint64_t)((const bf16_t*)p.A + (int64_t)z * p.sA), bw = (uint64_t)((const bf16_t*)p.W + (int64_t)z * p.sW);
+        dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+        dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+    }
+    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(lds_addr), "s"(desc)
+                     : "memory");
+    };
+    auto dma_tile = [&](int kt, int stage_idx) {
+        const unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
+        unsigned abytes = kbytes;
+        if (CONV) {
+            if (newtap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) aoff[i] = conv_tap_offset<CONV>(p, pv[i], pb[i], py[i], px[i], ky, kx, chunk);
+                newtap = false;
             }
+            abytes = (unsigned)c0 * 2u;
+        }
+        const unsigned stage = lds_base + (unsigned)stage_idx * kStage + (unsigned)wuni * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (RPP * 128), aoff[i] + abytes);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (i + 1 < NW || w_last) dma16(dW, stage + BM * 128 + i * (RPP * 128), woff[i] + kbytes);
+        }
+        if (CONV) {
+            c0 += BK;
+            if (c0 >= p.Cin) { c0 = 0; ++tap; newtap = true; }
+        }
+    };
+    // wait until all but `ahead` of this wave's tile DMA groups have landed (a group = NA + NW or NA + NW - 1 loads)
+    auto wait_tiles = [&](int ahead) {
+        if (ahead <= 0) { wait_vmcnt<0>(); return; }
+        if (w_last) {
+            if (ahead == 1) wait_vmcnt<NA + NW>();
+            else wait_vmcnt<2 * (NA + NW)>();
+        } else {
+            if (ahead == 1) wait_vmcnt<NA + NW - 1>();
+            else wait_vmcnt<2 * (NA + NW - 1)>();
+        }
+    };
+
+    const int frow = lane & 15, fq = lane >> 4;
+    auto compute = [&](int stage_idx) {
+        const unsigned char* sA = smem + stage_idx * kStage;
+        const unsigned char* sW = sA + BM * 128;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as_frag(*reinterpret_cast<const uint4*>(sA + lds_off(wr * 64 + i * 16 + frow, 4 * s2 + fq)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = as_frag(*reinterpret_cast<const uint4*>(sW + lds_off(wc * (TN * 16) + j * 16 + frow, 4 * s2 + fq)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nk > 0) {
+#pragma unroll
+        for (int t = 0; t < D; ++t)
+            if (t < nk) dma_tile(t, t);
+        int st_cur = 0, st_fill = D % NST;  // stage of tile kt / of tile kt+D
+        for (int kt = 0; kt < nk; ++kt) {
+            const int rem = nk - 1 - kt;
+            wait_tiles(rem < D - 1 ? rem : D - 1);
+            __syncthreads();  // the asm DMAs are invisible to hipcc, so this is a bare s_barrier (+ lgkmcnt for its own ds ops)
+            if (kt + D < nk) dma_tile(kt + D, st_fill);
+            compute(st_cur);
+            st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+            st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
         }
     }
+    epilogue_regs<TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,6 +770,22 @@ hipError_t launch_bf16(const GemmParams& p, int gz, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <bool CONV, int WM, int WN, int TN, int NST>
+hipError_t launch_ring(const GemmParams& p, int gz, hipStream_t s) {
+    constexpr int BM = WM * 64, BN = WN * TN * 16;
+    constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (smem > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<CONV, WM, WN, TN, NST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, gz);
+    gemm_ring_kernel<CONV, WM, WN, TN, NST><<<grid, WM * WN * 64, smem, s>>>(p);
+    return hipGetLastError();
+}
+
 template <bool CONV>
 int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     hipError_t e = hipSuccess;
@@ -604,7 +794,20 @@ int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipSt
         p.ksplit = pl.ksplit;
         p.ws = (float*)ws;
         const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
-        if (pl.bm == 128 && pl.bn == 160)
+        // pf 1xx selects a ring kernel (experiments): 1WS with W = waves-in-M (2|4), S = stages
+        if (pl.pf == 143 && pl.bn == 160) e = launch_ring<CONV, 4, 2, 5, 3>(p, gz, s);
+        else if (pl.pf == 143 && pl.bn == 128) e = launch_ring<CONV, 4, 2, 4, 3>(p, gz, s);
+        else if (pl.pf == 123 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 3>(p, gz, s);
+        else if (pl.pf == 124 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 4>(p, gz, s);
+        else if (pl.pf == 122 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 2>(p, gz, s);
+        else if (pl.pf == 122 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 2>(p, gz, s);
+        else if (pl.pf == 123 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 3>(p, gz, s);
+        else if (pl.pf == 124 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 4>(p, gz, s);
+        else if (pl.pf >= 100) { gmd_set_error("%s: ring variant %d not instantiated for BN=%d", name, pl.pf, pl.bn); return GMD_ERR_UNSUPPORTED; }
+        // default: two-stage LDS-DMA ring, 4 waves, two workgroups per CU (fastest of all variants measured on MI355X)
+        else if (pl.pf == 0 && pl.bm == 128 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 2>(p, gz, s);
+        else if (pl.pf == 0 && pl.bm == 128 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 2>(p, gz, s);
+        else if (pl.bm == 128 && pl.bn == 160)
             e = pl.pf == 0 ? launch_bf16<CONV, 128, 160, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 128, 160, 1>(p, gz, s) : launch_bf16<CONV, 128, 160, 2>(p, gz, s);
         else if (pl.bm == 128 && pl.bn == 128)
             e = pl.pf == 0 ? launch_bf16<CONV, 128, 128, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 128, 128, 1>(p, gz, s) : launch_bf16<CONV, 128, 128, 2>(p, gz, s);
