@@ -187,6 +187,34 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
             }
         }
     }
+    if constexpr (TN % 2 == 0) {
+        if (p.act == GMD_ACT_GEGLU) {
+            // W rows are interleaved in 16-row groups [value | gate] (host re-layout): tile j holds 16 value columns and
+            // tile j+1 the matching gate columns IN THE SAME LANE, so h * gelu_erf(g) is formed in registers and only the
+            // [M, N/2] product is written (GEGLU.forward of diffusers; N % 32 == 0 checked on the host).
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mw + i * 16 + frow;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int n = nw + j * 16 + fq * 4;  // interleaved column of the value group
+                    if (n >= p.N) continue;
+                    float o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float h = acc[i][j][e] * p.alpha + bz[j][e];
+                        const float g = acc[i][j + 1][e] * p.alpha + bz[j + 1][e];
+                        o4[e] = h * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+                    }
+                    const int no = (nw + j * 16) / 2 + fq * 4;  // output column in [0, N/2)
+                    bf16_t* o = (bf16_t*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + no;
+                    *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3]));
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = mw + i * 16 + frow;
@@ -728,11 +756,11 @@ struct Plan {
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
 // deep K (the 8x8 / 16x16 UNet levels: K up to 23040) are split along K.
-Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
+Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles) {
     Plan pl{64, 64, 0, 1};  // pf 0 = LDS-DMA pipeline (fastest measured); 1/2 = register-staged fallbacks
     if (M >= 96 && N >= 96) {
         pl.bm = 128;
-        pl.bn = (N % 160 == 0) ? 160 : 128;
+        pl.bn = (N % 160 == 0 && !pair_tiles) ? 160 : 128;  // GEGLU needs an even number of 16-column tiles per wave
     }
     const char* f = getenv("GMD_GEMM_FORCE");  // "bm,bn,pf,ksplit" (0 = keep heuristic) -- tuning experiments only
     int fbm = 0, fbn = 0, fpf = 0, fks = 0;
@@ -741,7 +769,7 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
     if (fpf) pl.pf = fpf == 9 ? 0 : fpf;  // 9 selects the LDS-DMA pipeline (pf 0)
     int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
     const int nk = K / BK;
-    if (batch == 1 && tiles < 160 && nk >= 24) {  // K >= 1536: the slab reduction (a second launch) must pay for itself
+    if (batch == 1 && tiles < 160 && nk >= 24 && !pair_tiles) {  // K >= 1536: the slab reduction (a second launch) must pay for itself
         int ks = (int)((384 + tiles - 1) / tiles);
         if (ks > nk / 8) ks = nk / 8;  // at least 8 K steps (512 channels) per slice
         if (ks > 16) ks = 16;
@@ -790,7 +818,7 @@ template <bool CONV>
 int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     hipError_t e = hipSuccess;
     if (dtype == GMD_BF16) {
-        const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0);
+        const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
         p.ksplit = pl.ksplit;
         p.ws = (float*)ws;
         const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
@@ -848,14 +876,19 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     if (M == 0 || N == 0 || batch == 0) return GMD_OK;
     const int kmul = dtype == GMD_BF16 ? 64 : 4, vec = dtype == GMD_BF16 ? 8 : 4;
     GMD_REQUIRE(K % kmul == 0, "gmd_gemm_nt: K=%d must be a multiple of %d", K, kmul);
-    GMD_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gmd_gemm_nt: leading dimension too small");
+    GMD_REQUIRE(lda >= K && ldw >= K && (ldc >= N || act == GMD_ACT_GEGLU), "gmd_gemm_nt: leading dimension too small");
     GMD_REQUIRE(lda % vec == 0 && ldw % vec == 0 && strideA % vec == 0 && strideW % vec == 0,
                 "gmd_gemm_nt: lda/ldw/strides must be multiples of %d elements", vec);
     GMD_REQUIRE(A && W && C && gmd_aligned16(A) && gmd_aligned16(W) && gmd_aligned16(C), "gmd_gemm_nt: null or unaligned pointer");
     GMD_REQUIRE(rowbias == nullptr || rows_per_group > 0, "gmd_gemm_nt: rows_per_group must be positive");
     GMD_REQUIRE(residual == nullptr || (ldr >= N && gmd_aligned16(residual)), "gmd_gemm_nt: bad residual");
     GMD_REQUIRE(residual == nullptr || out_dtype == dtype || dtype == GMD_F32, "gmd_gemm_nt: residual needs out_dtype == dtype");
-    GMD_REQUIRE(act == GMD_ACT_NONE || act == GMD_ACT_SILU, "gmd_gemm_nt: bad act %d", act);
+    GMD_REQUIRE(act == GMD_ACT_NONE || act == GMD_ACT_SILU || act == GMD_ACT_GEGLU, "gmd_gemm_nt: bad act %d", act);
+    if (act == GMD_ACT_GEGLU) {
+        GMD_REQUIRE(dtype == GMD_BF16 && out_dtype == GMD_BF16, "gmd_gemm_nt: GEGLU epilogue is implemented for bf16 only");
+        GMD_REQUIRE(N % 32 == 0 && ldc >= N / 2 && ldc % 4 == 0 && strideC % 4 == 0, "gmd_gemm_nt: GEGLU needs N %% 32 == 0 and ldc >= N/2");
+        GMD_REQUIRE(!residual && !rowbias, "gmd_gemm_nt: GEGLU epilogue takes no residual / rowbias");
+    }
     GMD_REQUIRE(batch <= 65535, "gmd_gemm_nt: batch too large");
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K;

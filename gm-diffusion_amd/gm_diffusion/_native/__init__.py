@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip
 ABI_VERSION = 2
 
 GMD_F32, GMD_BF16 = 0, 1
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 

@@ -348,6 +348,13 @@ class UNet2DConditionModel(_HipModule):
             t["v2"] = self._lin(f"{b}.attn2.to_v", False)[0]
             t["o2"] = self._lin(f"{b}.attn2.to_out.0")
             t["ff1"] = self._lin(f"{b}.ff.net.0.proj")
+            if self._dtype == torch.bfloat16:
+                # fused GEGLU epilogue: interleave value / gate rows in groups of 16 so both land in the same MFMA lane
+                wf, bf = self._raw[f"{b}.ff.net.0.proj.weight"], self._raw[f"{b}.ff.net.0.proj.bias"]
+                half = wf.shape[0] // 2
+                wi = torch.stack([wf[:half].reshape(half // 16, 16, -1), wf[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1)
+                bi = torch.stack([bf[:half].reshape(half // 16, 16), bf[half:].reshape(half // 16, 16)], 1).reshape(2 * half)
+                t["ff1"] = (self._act(wi), self._f32(bi))
             t["ff2"] = self._lin(f"{b}.ff.net.2")
             t["key"] = k
             return t
@@ -446,7 +453,10 @@ class UNet2DConditionModel(_HipModule):
         h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h)
         # GEGLU feed-forward
         n3 = ops.layernorm(h, *t["norm3"])
-        f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
+        if self._dtype == torch.bfloat16:
+            f = ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1], act=ops.ACT_GEGLU)  # h * gelu(g) formed in the GEMM epilogue
+        else:
+            f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
         h = ops.gemm_nt(f, t["ff2"][0], bias=t["ff2"][1], residual=h)
         return ops.gemm_nt(h, t["pout"][0], bias=t["pout"][1], residual=x.view(B * N, C)).view(B, N, C)
 

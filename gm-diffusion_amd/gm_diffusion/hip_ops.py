@@ -15,10 +15,10 @@ from __future__ import annotations
 import torch
 
 from . import profiling
-from ._native import ACT_NONE, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
+from ._native import ACT_GEGLU, ACT_NONE, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_SILU", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
+    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
     "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
@@ -110,7 +110,7 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     sA = M * K if a.dim() == 3 else 0
     sW = N * K if w.dim() == 3 else 0
     out_dtype = out_dtype or a.dtype
-    ldc = ldc or N
+    ldc = ldc or (N // 2 if act == ACT_GEGLU else N)  # the fused GEGLU epilogue writes [M, N/2]
     if out is None:
         out = torch.empty((batch, M, ldc) if batch > 1 or a.dim() == 3 or w.dim() == 3 else (M, ldc),
                           dtype=out_dtype, device=a.device)

@@ -43,6 +43,7 @@ extern "C" {
 /* epilogue activation for gmd_gemm_nt */
 #define GMD_ACT_NONE 0
 #define GMD_ACT_SILU 1
+#define GMD_ACT_GEGLU 2 /* bf16 only: W rows interleaved in 16-row [value|gate] groups; writes [M, N/2] = h * gelu_erf(g) */
 
 typedef void* gmd_stream_t;
 

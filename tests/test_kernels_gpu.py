@@ -423,3 +423,23 @@ def test_composed_attention(dtype, d, heads):
     got = composed_attention(q.to(DEV), 0, C, k.to(DEV), 0, C, vt.to(DEV), B, heads, d, Nq, Nk, d ** -0.5, dtype)
     ref = _attn_ref(q, k, v, heads, d ** -0.5)
     assert rel_err(got.float(), ref) < (2e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (4096, 640), (64, 1280), (33, 64)])
+def test_gemm_fused_geglu_epilogue(M, C):
+    """ff.net.0 (GEGLU) with the gate applied in the GEMM epilogue: rows of W interleaved [16 value | 16 gate]."""
+    o = ops()
+    g = torch.Generator().manual_seed(C + M)
+    x = torch.randn(M, C, generator=g).bfloat16()
+    w = (torch.randn(8 * C, C, generator=g) / math.sqrt(C)).bfloat16()
+    b = torch.randn(8 * C, generator=g)
+    half = 4 * C
+    wi = torch.stack([w[:half].reshape(half // 16, 16, -1), w[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1).contiguous()
+    bi = torch.stack([b[:half].reshape(half // 16, 16), b[half:].reshape(half // 16, 16)], 1).reshape(2 * half).contiguous()
+    got = o.gemm_nt(x.to(DEV), wi.to(DEV), bias=bi.to(DEV), act=o.ACT_GEGLU)
+    assert got.shape == (M, half)
+    y = x.double() @ w.double().t() + b.double()
+    ref = y[:, :half] * F.gelu(y[:, half:])
+    assert rel_err(got.float(), ref) < 1.5e-2
+    unfused = o.geglu(o.gemm_nt(x.to(DEV), w.to(DEV), bias=b.to(DEV)))
+    assert rel_err(got.float(), unfused.float()) < 1.5e-2
