@@ -538,7 +538,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so workgroup ids with
+    // equal id % 8 get a CONTIGUOUS run of tiles (bijective remap, cdna guide T1).  Tiles are numbered n-fastest, so
+    // the N-tiles of one row block and neighbouring row blocks (whose conv taps overlap) share one L2.
+    int m0, n0;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tiles_n = (p.N + BN - 1) / BN;
+        const int mt = L / tiles_n;
+        m0 = mt * BM;
+        n0 = (L - mt * tiles_n) * BN;
+    }
     const int z = p.ksplit > 1 ? 0 : blockIdx.z;
     const int ks = p.ksplit > 1 ? blockIdx.z : 0;
     const int srow = tid >> 3;                                    // 0 .. RPP-1
@@ -809,7 +821,7 @@ hipError_t launch_ring(const GemmParams& p, int gz, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, gz);
+    dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);  // 1-D tile index, remapped per XCD in the kernel
     gemm_ring_kernel<CONV, WM, WN, TN, NST><<<grid, WM * WN * 64, smem, s>>>(p);
     return hipGetLastError();
 }
