@@ -134,6 +134,79 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused GroupNorm(+SiLU), one workgroup per (sample, group) over the group's slab [HW][C/G]: exact two-pass mean /
+// variance (fixed reduction order: deterministic) and the normalised result written straight back -- ONE launch
+// instead of partial + finalize + apply, for slabs small enough to be re-read from L2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` from the previous use
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// The slab (<= 128 KiB, host-checked) is read three times -- sum, centred sum of squares, normalise -- the second
+// and third time out of L2; no register array, so the kernel stays small and many workgroups share a CU.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict__ X, T* __restrict__ Y, int HW, int C, int G,
+                                                            float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int silu) {
+    constexpr int EPW = sizeof(T) == 2 ? 2 : 1;  // elements per 4-byte word
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, wpr = cpg / EPW;       // words per pixel row of this group
+    const int total = HW * wpr;
+    const unsigned* Xw = reinterpret_cast<const unsigned*>(X + ((int64_t)b * HW) * C + (int64_t)g * cpg);
+    unsigned* Yw = reinterpret_cast<unsigned*>(Y + ((int64_t)b * HW) * C + (int64_t)g * cpg);
+    const int rw = C / EPW;                        // row stride in words
+    // item it = tid + 256 k -> (pixel, word-in-row), advanced incrementally (no division in the loops)
+    const int dq = kThreads / wpr, dr = kThreads - dq * wpr;
+    const int px0 = (int)threadIdx.x / wpr, j0 = (int)threadIdx.x - px0 * wpr;
+    float s = 0.f;
+    for (int it = threadIdx.x, px = px0, j = j0; it < total; it += kThreads) {
+        const unsigned w = Xw[(int64_t)px * rw + j];
+        if (EPW == 2) s += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+        else s += __uint_as_float(w);
+        px += dq; j += dr;
+        if (j >= wpr) { j -= wpr; ++px; }
+    }
+    const float n = (float)HW * (float)cpg;
+    const float mean = block_sum_256(s, red) / n;
+    float q = 0.f;
+    for (int it = threadIdx.x, px = px0, j = j0; it < total; it += kThreads) {
+        const unsigned w = Xw[(int64_t)px * rw + j];
+        if (EPW == 2) {
+            const float a = __uint_as_float(w << 16) - mean, c = __uint_as_float(w & 0xffff0000u) - mean;
+            q += a * a + c * c;
+        } else {
+            const float a = __uint_as_float(w) - mean;
+            q += a * a;
+        }
+        px += dq; j += dr;
+        if (j >= wpr) { j -= wpr; ++px; }
+    }
+    const float rstd = rsqrtf(block_sum_256(q, red) / n + eps);
+    for (int it = threadIdx.x, px = px0, j = j0; it < total; it += kThreads) {
+        const unsigned w = Xw[(int64_t)px * rw + j];
+        const int c0 = g * cpg + j * EPW;
+        if (EPW == 2) {
+            float a = (__uint_as_float(w << 16) - mean) * rstd * gamma[c0] + beta[c0];
+            float c = (__uint_as_float(w & 0xffff0000u) - mean) * rstd * gamma[c0 + 1] + beta[c0 + 1];
+            if (silu) { a = silu_f(a); c = silu_f(c); }
+            Yw[(int64_t)px * rw + j] = pack_bf16x2(a, c);
+        } else {
+            float a = (__uint_as_float(w) - mean) * rstd * gamma[c0] + beta[c0];
+            if (silu) a = silu_f(a);
+            Yw[(int64_t)px * rw + j] = __float_as_uint(a);
+        }
+        px += dq; j += dr;
+        if (j >= wpr) { j -= wpr; ++px; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers, exact two-pass variance.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int MAXCH>
@@ -272,6 +345,28 @@ int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, in
         GMD_REQUIRE(false, "gmd_groupnorm_apply: bad dtype %d", dtype);
     }
     GMD_CHECK_LAUNCH("gmd_groupnorm_apply");
+    return GMD_OK;
+}
+
+int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps, const float* gamma,
+                        const float* beta, int silu, gmd_stream_t stream) {
+    GMD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "gmd_groupnorm_fused: bad shape");
+    GMD_REQUIRE(X && Y && gamma && beta, "gmd_groupnorm_fused: null pointer");
+    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_groupnorm_fused: bad dtype %d", dtype);
+    GMD_REQUIRE(B <= 65535, "gmd_groupnorm_fused: batch too large");
+    const int cpg = C / G, epw = dtype == GMD_BF16 ? 2 : 1;
+    GMD_REQUIRE(cpg % epw == 0 && C % epw == 0 && (reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 3) == 0,
+                "gmd_groupnorm_fused: channels per group must be even for bf16");
+    const int64_t slab_bytes = HW * cpg * (dtype == GMD_BF16 ? 2 : 4);
+    if (slab_bytes > 128 * 1024 || HW * (int64_t)C >= (1LL << 31)) {
+        gmd_set_error("gmd_groupnorm_fused: group slab of %lld bytes is too large for the single-launch kernel (use gmd_groupnorm_stats + _apply)", (long long)slab_bytes);
+        return GMD_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(G, B);
+    if (dtype == GMD_BF16) gn_fused_kernel<bf16_t><<<grid, kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, (int)HW, C, G, eps, gamma, beta, silu);
+    else gn_fused_kernel<float><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, (int)HW, C, G, eps, gamma, beta, silu);
+    GMD_CHECK_LAUNCH("gmd_groupnorm_fused");
     return GMD_OK;
 }
 

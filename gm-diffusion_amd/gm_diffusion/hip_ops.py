@@ -19,7 +19,7 @@ from ._native import ACT_GEGLU, ACT_NONE, ACT_SILU, GMD_BF16, GMD_F32, HipExtens
 
 __all__ = [
     "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
-    "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "layernorm", "geglu", "timestep_embedding",
+    "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "groupnorm_split", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
 ]
@@ -227,7 +227,27 @@ def groupnorm_apply(x, B, ss, silu):
     return y
 
 
+GN_FUSED_MAX_SLAB = 24 * 1024  # bytes of one (sample, group) slab up to which the single-launch kernel wins (tools/bench_gn.py:
+# 9-18 us vs ~24-30 us for the three-launch path on the 16x16 / 8x8 UNet levels; beyond ~40 KiB the strided re-reads lose)
+
+
 def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
+    """GroupNorm(+SiLU).  Small group slabs (16x16 / 8x8 UNet levels) take the single-launch fused kernel;
+    larger ones the split-statistics path (partial + finalize + apply)."""
+    _dev(x, gamma, beta)
+    C = x.shape[-1]
+    HW = x.numel() // (B * C)
+    epw = 2 if x.dtype == torch.bfloat16 else 1
+    cpg = C // groups
+    if cpg % epw == 0 and HW * cpg * x.element_size() <= GN_FUSED_MAX_SLAB:
+        y = torch.empty_like(x)
+        check(lib().gmd_groupnorm_fused(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
+                                        _ptr(_f32(beta, "beta")), int(silu), _stream()), "gmd_groupnorm_fused")
+        return y
+    return groupnorm_apply(x, B, groupnorm_scale_shift(x, B, groups, gamma, beta, eps), silu)
+
+
+def groupnorm_split(x, B, groups, gamma, beta, eps, silu=False):
     return groupnorm_apply(x, B, groupnorm_scale_shift(x, B, groups, gamma, beta, eps), silu)
 
 

@@ -186,6 +186,11 @@ int gmd_groupnorm_stats(const void* X, int dtype, int B, int64_t HW, int C, int 
 /* Y = [silu](X*scale+shift) */
 int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, int C,
                         const float* scale_shift, int silu, gmd_stream_t stream);
+/* GroupNorm(+SiLU) in ONE launch: one workgroup per (sample, group) over the group's [HW][C/G] slab (exact two-pass
+ * variance, fixed reduction order; the slab is re-read from L2).  Returns GMD_ERR_UNSUPPORTED when the slab exceeds
+ * 128 KiB: use gmd_groupnorm_stats + gmd_groupnorm_apply then. */
+int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps,
+                        const float* gamma, const float* beta, int silu, gmd_stream_t stream);
 /* LayerNorm over the last dim (C % 8 == 0, C <= 2048) */
 int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C,
                   const float* gamma, const float* beta, float eps, gmd_stream_t stream);

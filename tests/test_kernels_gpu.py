@@ -206,7 +206,7 @@ def test_pack_unpack(dtype):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,HW,C,G", [(2, 64, 320, 32), (1, 4096, 320, 32), (2, 256, 1280, 32), (1, 64, 2560, 32),
-                                      (2, 100, 128, 32), (1, 16, 960, 32), (3, 37, 64, 8)])
+                                      (2, 100, 128, 32), (1, 16, 960, 32), (3, 37, 64, 8), (1, 4096, 960, 32), (2, 1024, 1920, 32), (1, 65536, 128, 32)])
 def test_groupnorm(dtype, B, HW, C, G):
     o = ops()
     g = torch.Generator().manual_seed(C + HW)
@@ -217,8 +217,10 @@ def test_groupnorm(dtype, B, HW, C, G):
         ref = F.group_norm(xn, G, gamma, beta, 1e-5)
         ref = F.silu(ref) if silu else ref
         ref = ref.reshape(B, C, HW).permute(0, 2, 1)
-        got = o.groupnorm(x.to(DEV), B, G, gamma.to(DEV), beta.to(DEV), 1e-5, silu=silu)
+        got = o.groupnorm(x.to(DEV), B, G, gamma.to(DEV), beta.to(DEV), 1e-5, silu=silu)  # fused single launch when it fits
         assert rel_err(got.float(), ref) < (2e-6 if dtype == torch.float32 else 6e-3)
+        got2 = o.groupnorm_split(x.to(DEV), B, G, gamma.to(DEV), beta.to(DEV), 1e-5, silu=silu)  # partial + finalize + apply
+        assert rel_err(got2.float(), ref) < (2e-6 if dtype == torch.float32 else 6e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
