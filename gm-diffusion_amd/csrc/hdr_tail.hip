@@ -155,6 +155,25 @@ __global__ __launch_bounds__(kThreads) void u8_kernel(const float* __restrict__ 
         out[i] = u8_trunc(in[i]);
 }
 
+// Radiance RGBE pixel (Ward's float2rgbe, the encoder behind cv2.imwrite("*.hdr") that the reference calls at
+// scripts/inference/generate_hdr.py:27-30): v = max(r,g,b); v < 1e-32 -> 0,0,0,0; else v = frexp(v,&e) * 256 / v;
+// bytes = (uint8)(c * v) (truncation), exponent byte = e + 128.
+__global__ __launch_bounds__(kThreads) void rgbe_kernel(const float* __restrict__ rgb, uint8_t* __restrict__ out, int64_t npix) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        // RGBE has no sign: negative components (the unclamped Eq. 1 can produce down to -1/64) are stored as 0
+        const float r = fmaxf(rgb[i * 3], 0.f), g = fmaxf(rgb[i * 3 + 1], 0.f), b = fmaxf(rgb[i * 3 + 2], 0.f);
+        float v = fmaxf(r, fmaxf(g, b));
+        uchar4 px = make_uchar4(0, 0, 0, 0);
+        if (v >= 1e-32f) {
+            int e;
+            const float m = frexpf(v, &e);
+            const float sc = m * 256.0f / v;
+            px = make_uchar4((uint8_t)(int)(r * sc), (uint8_t)(int)(g * sc), (uint8_t)(int)(b * sc), (uint8_t)(e + 128));
+        }
+        *reinterpret_cast<uchar4*>(out + i * 4) = px;
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t g = (n + kThreads - 1) / kThreads;
     if (g > 256 * 16) g = 256 * 16;
@@ -234,6 +253,15 @@ int gmd_discretize_u16(const float* in, float* out_float, uint16_t* out_codes, i
     GMD_REQUIRE(in && (out_float || out_codes), "gmd_discretize_u16: null pointer");
     u16_kernel<<<grid_for(n), kThreads, 0, (hipStream_t)stream>>>(in, out_float, out_codes, n);
     GMD_CHECK_LAUNCH("gmd_discretize_u16");
+    return GMD_OK;
+}
+
+int gmd_rgbe_encode(const float* rgb, uint8_t* out, int64_t npix, gmd_stream_t stream) {
+    GMD_REQUIRE(npix >= 0, "gmd_rgbe_encode: negative size");
+    if (npix == 0) return GMD_OK;
+    GMD_REQUIRE(rgb && out && (reinterpret_cast<uintptr_t>(out) & 3) == 0, "gmd_rgbe_encode: null or unaligned pointer");
+    rgbe_kernel<<<grid_for(npix), kThreads, 0, (hipStream_t)stream>>>(rgb, out, npix);
+    GMD_CHECK_LAUNCH("gmd_rgbe_encode");
     return GMD_OK;
 }
 

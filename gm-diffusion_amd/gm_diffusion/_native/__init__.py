@@ -32,6 +32,7 @@ SIGNATURES = {
     "gmd_stage1_chain": [P, P, P, I, L, F, P],
     "gmd_discretize_u16": [P, P, P, L, P],
     "gmd_quantize_u8": [P, P, L, P],
+    "gmd_rgbe_encode": [P, P, L, P],
     "gmd_latent_step": [P, P, P, P, P, P, I, L, I, F, P, F, I, F, F, F, F, F, P, P, P, P],
     "gmd_cfg_std_ratio": [P, I, L, F, P, P],
     "gmd_pack_unet_input": [P, I, P, I, I, L, I, P, I, I, P],

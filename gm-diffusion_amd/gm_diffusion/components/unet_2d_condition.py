@@ -295,6 +295,22 @@ class UNet2DConditionModel(_HipModule):
             json.dump({"_class_name": "UNet2DConditionModel", **{k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()}}, f, indent=2)
         save_file({k: v.contiguous() for k, v in self._raw.items()}, os.path.join(directory, "diffusion_pytorch_model.safetensors"))
 
+    def replace_conv_in(self, in_channels=8):
+        """The reference's ``_replace_unet_conv_in`` (scripts/inference/generate_hdr.py:75-94,
+        scripts/stage2/train_gm_unet.py:658-677): widen ``conv_in`` to ``in_channels`` by repeating the weight along
+        the input-channel axis and halving it; the bias is kept.  Returns self."""
+        w, b = self._raw["conv_in.weight"], self._raw["conv_in.bias"]
+        rep = in_channels // w.shape[1]
+        if rep * w.shape[1] != in_channels:
+            raise ValueError(f"in_channels={in_channels} is not a multiple of {w.shape[1]}")
+        sd = dict(self._raw)
+        sd["conv_in.weight"] = w.repeat(1, rep, 1, 1) * 0.5
+        sd["conv_in.bias"] = b.clone()
+        cfg = dict(self.config)
+        cfg["in_channels"] = in_channels
+        self._internal_dict = type(self._internal_dict)(cfg)
+        return self.load_state_dict(sd)
+
     def init_random(self, seed=1234):
         """Deterministic synthetic weights (uniform +-1/sqrt(fan_in), unit norms) for benchmarks; no checkpoint
         exists offline."""

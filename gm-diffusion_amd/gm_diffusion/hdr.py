@@ -28,9 +28,10 @@ def decode_to_hdr(vae, sdr_latent, gm_latent, qmax=99.0, eps=1 / 64, clamp=False
     hdr (Eq. 1), hdr_file (= hdr/(qmax+1)), hdr_u16 (round-half-even codes of clamp(hdr_file))."""
     inv = 1.0 / vae.config.scaling_factor
     B = sdr_latent.shape[0]
-    sdr_dec, H, W = vae.decode_nhwc(ops.tmo(_f32(sdr_latent), 5, mu=inv))
-    gm_dec, _, _ = vae.decode_nhwc(ops.tmo(_f32(gm_latent), 5, mu=inv))
-    return ops.hdr_tail(sdr_dec, gm_dec, 2, B, H, W, qmax=qmax, eps=eps, clamp=clamp, want=want)
+    # both latents go through the (shared) decoder as ONE batch of 2B: half the launches, fuller grids
+    both = torch.cat([_f32(sdr_latent), _f32(gm_latent)], 0)
+    dec, H, W = vae.decode_nhwc(ops.tmo(both, 5, mu=inv))  # [2B, H*W, 4] float32
+    return ops.hdr_tail(dec[:B], dec[B:], 2, B, H, W, qmax=qmax, eps=eps, clamp=clamp, want=want)
 
 
 def recompose(sdr_dec, gm_dec, qmax=99.0, eps=1 / 64, clamp=False, **kw):
@@ -46,3 +47,30 @@ def to_host(out):
 def _f32(x):
     x = x.contiguous()
     return x if x.dtype == torch.float32 else ops.cast(x, torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# file writers: the reference uses cv2.imwrite("*.hdr") / PIL; cv2 is absent here
+# ------------------------------------------------------------------------------------------------
+def save_hdr_image(hdr_file_rgb, path):
+    """Write one Radiance RGBE picture.  ``hdr_file_rgb``: [H,W,3] float32 device tensor, already divided by
+    (qmax+1) and in RGB order (= ``out['hdr_file'][i]``); this is what the reference's ``save_hdr_image``
+    (generate_hdr.py:27-30) hands to ``cv2.imwrite`` after its BGR swap.  Pixels are encoded on the device
+    (gmd_rgbe_encode); scanlines are written flat (uncompressed), which every Radiance reader accepts.
+    Negative values (possible with the unclamped Eq. 1) are stored as 0: RGBE has no sign."""
+    x = hdr_file_rgb.contiguous()
+    if x.dim() != 3 or x.shape[-1] != 3:
+        raise ValueError("save_hdr_image expects [H, W, 3]")
+    h, w = x.shape[0], x.shape[1]
+    px = ops.rgbe_encode(_f32(x)).cpu().numpy()
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n")
+        f.write(f"-Y {h} +X {w}\n".encode())
+        f.write(px.tobytes())
+
+
+def save_png_u8(u8_rgb, path):
+    """[H,W,3] uint8 device/host tensor -> PNG (generate_hdr.py:244-245 uses PIL the same way)."""
+    from PIL import Image
+
+    Image.fromarray(u8_rgb.cpu().numpy() if torch.is_tensor(u8_rgb) else u8_rgb).save(path)

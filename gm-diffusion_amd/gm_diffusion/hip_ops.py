@@ -435,3 +435,14 @@ def gemm_raw(a_ptr, w_ptr, c_ptr, dtype, out_dtype, M, N, K, lda, ldw, ldc, batc
     check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, dtype_code(dtype), dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
                             sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, 0, None, 0, 0, float(alpha), act, None, 0, _stream()),
           "gmd_gemm_nt")
+
+
+def rgbe_encode(rgb):
+    """float32 [..., 3] non-negative RGB -> uint8 [..., 4] Radiance RGBE pixels."""
+    _dev(rgb)
+    _f32(rgb, "rgbe input")
+    if rgb.shape[-1] != 3:
+        raise HipExtensionError("rgbe_encode expects [..., 3]")
+    out = torch.empty(rgb.shape[:-1] + (4,), dtype=torch.uint8, device=rgb.device)
+    check(lib().gmd_rgbe_encode(_ptr(rgb), _ptr(out), rgb.numel() // 3, _stream()), "gmd_rgbe_encode")
+    return out

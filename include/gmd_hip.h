@@ -84,6 +84,9 @@ int gmd_gamut_compress(const float* in, float* out, int B, int64_t HW, gmd_strea
 int gmd_stage1_chain(const float* gm, const float* sdr, float* out, int B, int64_t HW, float qmax, gmd_stream_t stream);
 /* augmentations.py:38-41 discretize_to_uint16; out_float and/or out_codes may be NULL */
 int gmd_discretize_u16(const float* in, float* out_float, uint16_t* out_codes, int64_t n, gmd_stream_t stream);
+/* Radiance RGBE pixels of float RGB [npix,3] -> [npix,4] bytes (Ward's float2rgbe, the encoder behind
+ * cv2.imwrite("*.hdr"), scripts/inference/generate_hdr.py:27-30); negative components are stored as 0 */
+int gmd_rgbe_encode(const float* rgb, uint8_t* out, int64_t npix, gmd_stream_t stream);
 /* generate_hdr.py:244-245 (x*255).astype(uint8) */
 int gmd_quantize_u8(const float* in, uint8_t* out, int64_t n, gmd_stream_t stream);
 

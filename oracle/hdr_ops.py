@@ -155,3 +155,26 @@ def stage1_chain(gm_nchw, sdr_nchw, qmax=49):
     fix_mulog_tmo -> gamut_compress."""
     hdr = apply_gm_to_sdr(gm_nchw, sdr_nchw, qmax=qmax, clamp=True)
     return gamut_compress(fix_mulog_tmo(hdr, qmax))
+
+
+def rgbe_encode(rgb):
+    """Radiance RGBE pixels (G. Ward's ``float2rgbe``, the encoder inside OpenCV's HDR writer that the reference
+    calls through ``cv2.imwrite`` at generate_hdr.py:27-30; cv2 is not installed here, so this restates the published
+    algorithm): v = max(r,g,b); v < 1e-32 -> (0,0,0,0); else (m, e) = frexp(v), s = m*256/v,
+    bytes = trunc(c*s), exponent byte = e + 128.  Negative components are stored as 0 (RGBE has no sign)."""
+    x = np.maximum(_f32(rgb), F32(0))
+    v = x.max(axis=-1)
+    m, e = np.frexp(v)
+    ok = v >= F32(1e-32)
+    s = (m.astype(F32) * F32(256.0) / np.where(ok, v, F32(1))).astype(F32)
+    out = np.zeros(x.shape[:-1] + (4,), np.uint8)
+    out[..., :3] = np.where(ok[..., None], (x * s[..., None]).astype(np.int32), 0).astype(np.uint8)
+    out[..., 3] = np.where(ok, e + 128, 0).astype(np.uint8)
+    return out
+
+
+def rgbe_decode(px):
+    """Inverse of :func:`rgbe_encode` (Ward's ``rgbe2float`` without the +0.5 bias OpenCV also omits)."""
+    px = np.asarray(px)
+    f = np.ldexp(F32(1.0), px[..., 3].astype(np.int32) - (128 + 8)).astype(F32)
+    return np.where(px[..., 3:4] == 0, F32(0), px[..., :3].astype(F32) * f[..., None]).astype(F32)

@@ -310,3 +310,16 @@ def test_checkpoint_directory_roundtrip(tmp_path):
     assert s.config.skip_prk_steps and s.config.steps_offset == 1
     d = DDPMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")  # generate_hdr.py:162 loads DDPM from the PNDM config
     assert d.config.beta_schedule == "scaled_linear"
+
+
+def test_replace_conv_in_matches_reference_recipe():
+    from gm_diffusion.components import UNet2DConditionModel
+
+    ou = fixtures.build_unet("tiny", 4)
+    hu = UNet2DConditionModel(**vars(ou.config))
+    hu.load_state_dict(ou.state_dict())
+    w4, b4 = ou.state_dict()["conv_in.weight"], ou.state_dict()["conv_in.bias"]
+    hu.replace_conv_in(8)
+    assert hu.config.in_channels == 8
+    assert torch.equal(hu.state_dict()["conv_in.weight"], w4.repeat(1, 2, 1, 1) * 0.5)  # generate_hdr.py:79-81
+    assert torch.equal(hu.state_dict()["conv_in.bias"], b4)

@@ -445,3 +445,22 @@ def test_gemm_fused_geglu_epilogue(M, C):
     assert rel_err(got.float(), ref) < 1.5e-2
     unfused = o.geglu(o.gemm_nt(x.to(DEV), w.to(DEV), bias=b.to(DEV)))
     assert rel_err(got.float(), unfused.float()) < 1.5e-2
+
+
+def test_rgbe_encode_bit_exact_and_file(tmp_path):
+    from gm_diffusion import hdr
+    from oracle import hdr_ops as H
+
+    o = ops()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(37, 53, 3, generator=g) * 30 - 0.2
+    x[0, 0] = 0.0
+    x[0, 1] = torch.tensor([1e-35, 0.0, 0.0])
+    got = o.rgbe_encode(x.to(DEV)).cpu().numpy()
+    assert np.array_equal(got, H.rgbe_encode(x.numpy()))  # byte work: bit exact
+    path = tmp_path / "a.hdr"
+    hdr.save_hdr_image(x.to(DEV), str(path))
+    raw = open(path, "rb").read()
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 37 +X 53\n"
+    assert raw.startswith(head) and len(raw) == len(head) + 37 * 53 * 4
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(37, 53, 4), got)

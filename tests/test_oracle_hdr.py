@@ -79,3 +79,14 @@ def test_tail_composition_shapes():
     assert t["hdr"].shape == (2, 6, 8, 3) and t["sdr_u8"].dtype == np.uint8
     assert np.array_equal(t["hdr_file"], (t["hdr"] / np.float32(100)).astype(np.float32))
     assert np.array_equal(H.save_hdr_scale(t["hdr"], 99), t["hdr_file"][..., [2, 1, 0]])
+
+
+def test_rgbe_known_answers_and_roundtrip():
+    x = np.array([[1, 1, 1], [0.5, 0.25, 0.125], [0, 0, 0], [1e-33, 0, 0], [3.7, 0.2, -0.01], [255.9, 1, 1]], np.float32)
+    e = H.rgbe_encode(x)
+    assert e.tolist() == [[128, 128, 128, 129], [128, 64, 32, 128], [0, 0, 0, 0], [0, 0, 0, 0], [236, 12, 0, 130], [255, 1, 1, 136]]
+    rng = np.random.default_rng(0)
+    y = (rng.random((64, 64, 3), dtype=np.float32) * 40).astype(np.float32)
+    d = H.rgbe_decode(H.rgbe_encode(y))
+    # 8-bit mantissa relative to the pixel maximum, truncation: error < max/128 per component
+    assert np.all(y - d >= 0) and np.all(y - d <= y.max(-1, keepdims=True) / 128 + 1e-6)
