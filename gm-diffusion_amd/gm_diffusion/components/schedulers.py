@@ -159,9 +159,11 @@ class PNDMScheduler(_SchedulerBase):
             hist = [e for e in reversed(self.ets[-3:])] if self.counter != 1 else [self.ets[-1]]
             x = sample.contiguous()
             nh = {0: 0, 1: 1, 2: 1, 3: 2, 4: 3}[mode]
-            _, prev_sample, _ = ops.latent_step(model_output.contiguous(), x, mode, (sc.item(), ad.item(), dn.item(), 1.0, 0.0),
-                                                False, 1.0, cur_sample=self.cur_sample, hist=hist[:nh])
-            self._commit(mode, model_output, sample)
+            eps_copy, prev_sample, _ = ops.latent_step(model_output.contiguous(), x, mode, (sc.item(), ad.item(), dn.item(), 1.0, 0.0),
+                                                       False, 1.0, cur_sample=self.cur_sample, hist=hist[:nh])
+            # keep the kernel's private copy in the history: `model_output` may be the static output buffer of a
+            # captured graph that the next replay overwrites
+            self._commit(mode, eps_copy, sample)
         else:
             e = (self.ets[-3:] + [model_output]) if self.counter != 1 else self.ets
             smp = sample

@@ -165,6 +165,18 @@ def composed_attention(q, q_col, ldq, k, k_col, ldk, vt, B, H, d, nq, nk, scale,
     return out
 
 
+class _GraphedForward:
+    """A captured UNet forward: static input ``x``, static output ``out``, ``replay()`` on the current stream."""
+
+    x = None
+    out = None
+    graph = None
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
 class UNet2DConditionModel(_HipModule):
     config_name = "config.json"
     _defaults = SD15_UNET_DEFAULTS
@@ -187,6 +199,9 @@ class UNet2DConditionModel(_HipModule):
         self._init_module()
         self._kv_cache = {}
         self._t_dev = None
+        self._capturing = False
+        self._transformers = []
+        self._graphs = {}
 
     # ------------------------------------------------------------------------------------------
     # structure
@@ -340,6 +355,7 @@ class UNet2DConditionModel(_HipModule):
         w["te2"] = self._lin("time_embedding.linear_2")
 
         te_w, te_b = [], []
+        self._transformers = []
 
         def resnet(k):
             r = dict(n1=self._norm(k + ".norm1"), c1=self._conv3(k + ".conv1"), n2=self._norm(k + ".norm2"), c2=self._conv3(k + ".conv2"))
@@ -373,6 +389,7 @@ class UNet2DConditionModel(_HipModule):
                 t["ff1"] = (self._act(wi), self._f32(bi))
             t["ff2"] = self._lin(f"{b}.ff.net.2")
             t["key"] = k
+            self._transformers.append(t)
             return t
 
         downs, ups = self._layout()
@@ -398,6 +415,7 @@ class UNet2DConditionModel(_HipModule):
         # all ResnetBlock2D.time_emb_proj layers as ONE [sum(Cout), 1280] GEMM per forward
         w["te_all"] = (self._act(torch.cat(te_w, 0)), self._f32(torch.cat(te_b, 0)))
         self._kv_cache = {}
+        self._graphs = {}
         self._t_dev = torch.zeros(1, dtype=torch.float32, device=self._device)
         return w
 
@@ -432,19 +450,34 @@ class UNet2DConditionModel(_HipModule):
         return composed_attention(qk, 0, 2 * C, qk, C, 2 * C, vt, B, heads, d, N, N, scale, self._dtype)
 
     def _cross_kv(self, t, ehs):
-        """K and V^T of the text tokens: constant over the whole denoising loop, so cached per embedding tensor."""
-        key = (t["key"], ehs.data_ptr(), ehs._version, tuple(ehs.shape))
-        hit = self._kv_cache.get(t["key"])
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[2]
+        """K and V^T of the text tokens: constant over the whole denoising loop, so computed once per embedding tensor.
+        The buffers are persistent per (layer, shape) and rewritten in place for new embeddings, so a captured HIP
+        graph of the forward keeps reading valid addresses."""
+        key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
+        ent = self._kv_cache.get(t["key"])
+        if ent is not None and ent["key"] == key:
+            return ent["kc"], ent["vt"]
+        if self._capturing:
+            raise HipExtensionError("cross-attention K/V must be prepared (update_context) before graph capture")
         B, L, E = ehs.shape
         C = t["k2"].shape[0]
-        kc = ops.gemm_nt(ehs.view(B * L, E), t["k2"]).view(B, L, C)
         lpad = _pad_to(L, 8 if self._dtype == torch.bfloat16 else 4)
-        vt = torch.zeros((B, C, lpad), dtype=self._dtype, device=ehs.device)
-        ops.gemm_nt(t["v2"], ehs, out=vt, ldc=lpad)
-        self._kv_cache[t["key"]] = (key, kc, vt, ehs)  # holding `ehs` keeps its address from being recycled
-        return kc, vt
+        if ent is None or tuple(ent["kc"].shape) != (B, L, C) or ent["kc"].dtype != self._dtype:
+            ent = dict(kc=torch.empty((B, L, C), dtype=self._dtype, device=ehs.device),
+                       vt=torch.zeros((B, C, lpad), dtype=self._dtype, device=ehs.device))
+            self._kv_cache[t["key"]] = ent
+        ops.gemm_nt(ehs.view(B * L, E), t["k2"], out=ent["kc"].view(B * L, C))
+        ops.gemm_nt(t["v2"], ehs, out=ent["vt"], ldc=lpad)
+        ent["key"] = key
+        ent["ehs"] = ehs  # holding `ehs` keeps its address from being recycled while the key is valid
+        return ent["kc"], ent["vt"]
+
+    def update_context(self, ehs):
+        """Prepare the cross-attention K / V^T of every transformer block for these text hidden states (eager,
+        in place).  Called once per pipeline call; required before replaying a captured forward."""
+        self._ensure()
+        for t in self._transformers:
+            self._cross_kv(t, ehs)
 
     def _transformer(self, t, x, B, H, W, ehs):
         C = x.shape[-1]
@@ -482,6 +515,12 @@ class UNet2DConditionModel(_HipModule):
         self._ensure()
         t = float(timestep)
         self._t_dev.copy_(torch.tensor([t], dtype=torch.float32), non_blocking=False)
+
+    def set_timestep_from(self, ts_dev, i):
+        """Device-to-device variant: copy element ``i`` of a float32 device vector of timesteps (no host round trip,
+        so the host can run ahead of the GPU)."""
+        self._ensure()
+        self._t_dev.copy_(ts_dev[i:i + 1], non_blocking=True)
 
     def forward_packed(self, x, B, H, W, encoder_hidden_states):
         """x: packed channels-last input [B, H*W, cin_pad]; the timestep must already be in ``_t_dev``.
@@ -522,6 +561,43 @@ class UNet2DConditionModel(_HipModule):
         y, _, _ = ops.conv3x3(x, w["conv_out"][0], B, H, W, bias=w["conv_out"][1], out_dtype=torch.float32)
         return ops.unpack_nchw(y, B, c.out_channels, H, W)
 
+    def graphed_forward(self, B, H, W, ehs):
+        """Capture ``forward_packed`` for this (batch, latent size) into a HIP graph (one per shape, cached).
+        Returns an object with ``.x`` (static packed-input buffer: fill it with ``pack_input(..., out=g.x)``) and
+        ``.replay()`` -> float32 eps [B, out_channels, H, W] (static output buffer).  The timestep is read from the
+        device scalar written by ``set_timestep``; the text conditioning from the in-place K / V^T buffers written by
+        ``update_context`` -- both outside the graph, so one capture serves every step and every prompt."""
+        self._ensure()
+        self.update_context(ehs)
+        key = (B, H, W, tuple(ehs.shape))
+        g = self._graphs.get(key)
+        if g is not None:
+            return g
+        from .. import profiling
+
+        if profiling.active() is not None:
+            raise HipExtensionError("graph capture with an active KernelTimer is not supported")
+        g = _GraphedForward()
+        g.x = torch.empty((B, H * W, self._cin_pad), dtype=self._dtype, device=self._device)
+        g.x.zero_()
+        cur = torch.cuda.current_stream(self._device)
+        side = torch.cuda.Stream(device=self._device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up on a side stream: one-time attribute calls, workspaces, allocator pools
+            for _ in range(2):
+                self.forward_packed(g.x, B, H, W, ehs)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self._device)
+        g.graph = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g.graph):
+                g.out = self.forward_packed(g.x, B, H, W, ehs)
+        finally:
+            self._capturing = False
+        self._graphs[key] = g
+        return g
+
     def prepare_context(self, encoder_hidden_states):
         """Cast text-encoder hidden states to the UNet dtype once (HIP cast kernel)."""
         self._ensure()
@@ -535,7 +611,7 @@ class UNet2DConditionModel(_HipModule):
             ehs = ehs.float()
         return ops.cast(ehs, self._dtype)
 
-    def pack_input(self, sample, dup=1):
+    def pack_input(self, sample, dup=1, out=None):
         """sample: float32 NCHW tensor, or a tuple ``(cond, x)`` concatenated on channels (conditioning first:
         stable_diffusion_gm.py:1045, dual_unet.py:1080); dup=2 duplicates the batch for CFG (gm.py:1047)."""
         self._ensure()
@@ -547,7 +623,7 @@ class UNet2DConditionModel(_HipModule):
         nch = a.shape[1] + (0 if b is None else b.shape[1])
         if nch != self.config.in_channels:
             raise ValueError(f"UNet expects {self.config.in_channels} input channels, got {nch}")
-        return ops.pack_unet_input(a.contiguous(), None if b is None else b.contiguous(), dup, self._cin_pad, self._dtype)
+        return ops.pack_unet_input(a.contiguous(), None if b is None else b.contiguous(), dup, self._cin_pad, self._dtype, out=out)
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
                  added_cond_kwargs=None, return_dict=True, **kwargs):

@@ -300,15 +300,19 @@ def cast(x, dtype):
 # ----------------------------------------------------------------------------------------------
 # latent-side
 # ----------------------------------------------------------------------------------------------
-def pack_unet_input(src0, src1, dup, cp, dtype):
-    """src0 [B,C0,h,w] (+ src1 [B,C1,h,w]) float32 NCHW -> [dup*B, h*w, cp] channels-last of `dtype`."""
-    _dev(src0, src1)
+def pack_unet_input(src0, src1, dup, cp, dtype, out=None):
+    """src0 [B,C0,h,w] (+ src1 [B,C1,h,w]) float32 NCHW -> [dup*B, h*w, cp] channels-last of `dtype`
+    (written into `out` when given: the static input buffer of a captured graph)."""
+    _dev(src0, src1, out)
     _f32(src0, "src0")
     _f32(src1, "src1")
     B, c0 = src0.shape[0], src0.shape[1]
     hw = src0.shape[2] * src0.shape[3]
     c1 = 0 if src1 is None else src1.shape[1]
-    out = torch.empty((dup * B, hw, cp), dtype=dtype, device=src0.device)
+    if out is None:
+        out = torch.empty((dup * B, hw, cp), dtype=dtype, device=src0.device)
+    elif tuple(out.shape) != (dup * B, hw, cp) or out.dtype != dtype:
+        raise HipExtensionError("pack_unet_input: `out` has the wrong shape/dtype")
     check(lib().gmd_pack_unet_input(_ptr(src0), c0, _ptr(src1), c1, B, hw, dup, _ptr(out), cp, dtype_code(dtype), _stream()),
           "gmd_pack_unet_input")
     return out

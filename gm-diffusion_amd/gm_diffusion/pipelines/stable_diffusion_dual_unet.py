@@ -36,9 +36,10 @@ __all__ = ["StableDiffusionDualUNetPipeline", "rescale_noise_cfg", "retrieve_tim
 
 
 class StableDiffusionDualUNetPipeline(_GMPipelineBase):
-    # Optional: run the GM UNet on a second HIP stream one step behind the SDR stream.  Measured on MI355X (bench.py
-    # --no-overlap A/B): 2.81 vs 2.85 images/s -- the kernels of one stream already occupy the chip, so it is off by default.
-    overlap_streams = False
+    # Run the GM UNet on a second HIP stream, one step behind the SDR UNet (GM(i) needs only x0_i, SDR(i+1) only
+    # latents_{i+1}).  Measured on MI355X (bench.py): eager launches 3.04 vs 3.04 images/s (the host, ~10 us per launch,
+    # cannot keep two streams fed); with each forward replayed from a captured HIP graph 3.04 -> 3.86 images/s.
+    overlap_streams = True
 
     def __init__(self, vae, text_encoder, tokenizer, unet, gm_unet, scheduler, safety_checker, feature_extractor,
                  image_encoder=None, requires_safety_checker: bool = True):
@@ -132,6 +133,12 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
             # kernels overlap (the batch-B GM kernels alone cannot fill 256 CUs).
             sdr_stream = torch.cuda.current_stream(latents.device)
             gm_stream = self._gm_stream(latents.device) if self.overlap_streams else sdr_stream
+            ts_host = [int(v) for v in timesteps.tolist()]          # host copy: no device sync inside the loop
+            ts_dev = timesteps.to(device=latents.device, dtype=torch.float32)
+            g_sdr = g_gm = None
+            if self._graphs_ok():
+                g_sdr = self.unet.graphed_forward((2 if do_cfg else 1) * latents.shape[0], h, w, ctx)
+                g_gm = self.gm_unet.graphed_forward(latents.shape[0], h, w, gm_ctx)
             gm_stream.wait_stream(sdr_stream)
 
         with self.progress_bar(total=num_inference_steps) as progress_bar:
@@ -139,19 +146,19 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                 if self.interrupt:
                     continue
                 if fused:
-                    x = self.unet.pack_input(latents, dup=2 if do_cfg else 1)
-                    self.unet.set_timestep(t)
-                    sdr_noise_pred = self.unet.forward_packed(x, x.shape[0], h, w, ctx)
+                    x = self.unet.pack_input(latents, dup=2 if do_cfg else 1, out=g_sdr.x if g_sdr else None)
+                    self.unet.set_timestep_from(ts_dev, i)
+                    sdr_noise_pred = g_sdr.replay() if g_sdr else self.unet.forward_packed(x, x.shape[0], h, w, ctx)
                     pre_step = latents
-                    latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, t, pre_step, do_cfg, self.guidance_scale,
+                    latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, ts_host[i], pre_step, do_cfg, self.guidance_scale,
                                                                    self.guidance_rescale if do_cfg else 0.0, want_x0=True)
                     with torch.cuda.stream(gm_stream):
                         gm_stream.wait_stream(sdr_stream)  # x0_i is ready
                         x0_latent.record_stream(gm_stream)
-                        gx = self.gm_unet.pack_input((x0_latent, gm_latents), dup=1)
-                        self.gm_unet.set_timestep(t)
-                        gm_noise_pred = self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
-                        gm_latents = self.gm_scheduler.step(gm_noise_pred, t, gm_latents, return_dict=False)[0]
+                        gx = self.gm_unet.pack_input((x0_latent, gm_latents), dup=1, out=g_gm.x if g_gm else None)
+                        self.gm_unet.set_timestep_from(ts_dev, i)
+                        gm_noise_pred = g_gm.replay() if g_gm else self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
+                        gm_latents = self.gm_scheduler.step(gm_noise_pred, ts_host[i], gm_latents, return_dict=False)[0]
                 else:
                     latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
                     latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)

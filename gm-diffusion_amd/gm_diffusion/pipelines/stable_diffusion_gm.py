@@ -298,6 +298,13 @@ class _GMPipelineBase(DiffusionPipeline):
         bf16 configuration: the UNet casts while packing its input); host tensors keep the reference's choice."""
         return torch.float32 if torch.device(device).type == "cuda" else prompt_embeds.dtype
 
+    use_hip_graphs = True  # capture each UNet forward once per shape and replay it (device path only)
+
+    def _graphs_ok(self):
+        from .. import profiling
+
+        return self.use_hip_graphs and profiling.active() is None
+
     def _use_fused(self, latents, unet, scheduler):
         from ..components.unet_2d_condition import UNet2DConditionModel
 
@@ -399,6 +406,10 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
         if fused:
             ctx = self.unet.prepare_context(prompt_embeds)
             sdr_f32 = sdr_latent.to(device=latents.device, dtype=torch.float32).contiguous()
+            ts_host = [int(v) for v in timesteps.tolist()]          # host copy: no device sync inside the loop
+            ts_dev = timesteps.to(device=latents.device, dtype=torch.float32)
+            hw = latents.shape[-2:]
+            graph = self.unet.graphed_forward((2 if do_cfg else 1) * latents.shape[0], hw[0], hw[1], ctx) if self._graphs_ok() else None
 
         with self.progress_bar(total=num_inference_steps) as progress_bar:
             for i, t in enumerate(timesteps):
@@ -406,11 +417,10 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
                     continue
                 if fused:
                     # concat(sdr, gm) + CFG duplicate + cast fused into the input pack; CFG/rescale/PLMS in one kernel
-                    x = self.unet.pack_input((sdr_f32, latents), dup=2 if do_cfg else 1)
-                    self.unet.set_timestep(t)
-                    hw = latents.shape[-2:]
-                    noise_pred = self.unet.forward_packed(x, x.shape[0], hw[0], hw[1], ctx)
-                    latents, _ = self.scheduler.fused_step(noise_pred, t, latents, do_cfg, self.guidance_scale,
+                    x = self.unet.pack_input((sdr_f32, latents), dup=2 if do_cfg else 1, out=graph.x if graph else None)
+                    self.unet.set_timestep_from(ts_dev, i)
+                    noise_pred = graph.replay() if graph else self.unet.forward_packed(x, x.shape[0], hw[0], hw[1], ctx)
+                    latents, _ = self.scheduler.fused_step(noise_pred, ts_host[i], latents, do_cfg, self.guidance_scale,
                                                            self.guidance_rescale if do_cfg else 0.0)
                 else:
                     cat_latents = torch.cat([sdr_latent, latents], dim=1)
@@ -437,6 +447,7 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
                         prompt_embeds = new_pe
                         if fused:
                             ctx = self.unet.prepare_context(prompt_embeds)
+                            self.unet.update_context(ctx)
                     negative_prompt_embeds = callback_outputs.pop("negative_prompt_embeds", negative_prompt_embeds)
 
                 if i == len(timesteps) - 1 or ((i + 1) > num_warmup_steps and (i + 1) % self.scheduler.order == 0):
