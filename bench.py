@@ -164,9 +164,11 @@ def main():
     if not a.no_kernel_timing and rank == 0:
         timer = profiling.KernelTimer()
         profiling.set_timer(timer)  # an active timer makes the pipeline take the eager (non-graph) path
+        pipe.overlap_streams = False  # one stream: an event pair then brackets exactly one kernel running alone
         step()
         torch.cuda.synchronize()
         profiling.set_timer(None)
+        pipe.overlap_streams = not a.no_overlap
     if world > 1:
         dist.barrier()
     if world > 1:
@@ -188,8 +190,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                     "launches": dom["launches"], "avg_launch_us": round(dom["avg_us"], 2),
                     "flops_per_launch_avg": round(dom["flops"] / dom["launches"]),
-                    "measured": "HIP events around every conv3x3 launch of one extra eager step after the timed region "
-                                "(the timed region replays HIP graphs, which events cannot enter)",
+                    "measured": "HIP events around every conv3x3 launch of one extra eager, single-stream step after the timed "
+                                "region (the timed region replays HIP graphs on two streams, which events cannot enter)",
                     "share_of_instrumented_kernel_time": round(dom["ms"] / sum(v["ms"] for v in full.values()), 3)}
         res = {
             "metric": "HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet", "value": round(total * a.steps / elapsed, 4),
