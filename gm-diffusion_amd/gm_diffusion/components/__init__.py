@@ -7,10 +7,10 @@ Pipeline components for the MI355X build: the classes a reference user would imp
 from .autoencoder_kl import AutoencoderKL
 from .configuration import ConfigMixin, FrozenDict
 from .image_processor import StableDiffusionPipelineOutput, VaeImageProcessor, randn_tensor
-from .schedulers import DDPMScheduler, PNDMScheduler
+from .schedulers import DDPMScheduler, DPMSolverMultistepScheduler, PNDMScheduler
 from .unet_2d_condition import UNet2DConditionModel
 
 __all__ = [
-    "AutoencoderKL", "UNet2DConditionModel", "PNDMScheduler", "DDPMScheduler", "VaeImageProcessor",
+    "AutoencoderKL", "UNet2DConditionModel", "PNDMScheduler", "DDPMScheduler", "DPMSolverMultistepScheduler", "VaeImageProcessor",
     "StableDiffusionPipelineOutput", "randn_tensor", "FrozenDict", "ConfigMixin",
 ]

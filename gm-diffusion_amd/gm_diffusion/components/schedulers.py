@@ -291,3 +291,128 @@ class DDPMScheduler(_SchedulerBase):
             v = self._get_variance(t).to(dev)
             prev = prev + (v * noise if self.config.variance_type == "fixed_small_log" else (v ** 0.5) * noise)
         return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)
+
+
+class DPMSolverMultistepScheduler(_SchedulerBase):
+    """DPM-Solver++ multistep scheduler: the one the reference swaps in for the dual-UNet text->HDR runs
+    (``DPMSolverMultistepScheduler.from_config(pipeline.scheduler.config)``,
+    scripts/inference/experiments/formal_improved.py:195; scripts/stage2/experiments/scheduler_tuning.py:190-201).
+    Implements diffusers' ``dpmsolver++`` / ``midpoint`` / epsilon-prediction path with ``solver_order`` 1-2,
+    ``lower_order_final`` and ``final_sigmas_type`` zero / sigma_min; Karras / exponential / beta sigma schedules,
+    SDE variants and thresholding raise NotImplementedError.  A host-side state machine over the scheduler protocol:
+    ``step`` runs as torch expressions on whatever device holds the latents (the fused HIP latent-step kernel covers
+    PNDM)."""
+
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                     solver_order=2, prediction_type="epsilon", thresholding=False, dynamic_thresholding_ratio=0.995,
+                     sample_max_value=1.0, algorithm_type="dpmsolver++", solver_type="midpoint", lower_order_final=True,
+                     euler_at_final=False, use_karras_sigmas=False, use_exponential_sigmas=False, use_beta_sigmas=False,
+                     final_sigmas_type="zero", timestep_spacing="linspace", steps_offset=0, clip_sample=False)
+
+    def __init__(self, **kwargs):
+        cfg = dict(self._defaults)
+        bad = [k for k in kwargs if k not in cfg]
+        if bad:
+            raise TypeError(f"DPMSolverMultistepScheduler: unexpected arguments {bad}")
+        cfg.update(kwargs)
+        self.register_to_config(**cfg)
+        if (cfg["algorithm_type"] != "dpmsolver++" or cfg["solver_type"] != "midpoint" or cfg["prediction_type"] != "epsilon"
+                or cfg["thresholding"] or cfg["use_karras_sigmas"] or cfg["use_exponential_sigmas"] or cfg["use_beta_sigmas"]
+                or cfg["euler_at_final"] or cfg["solver_order"] not in (1, 2)):
+            raise NotImplementedError("only dpmsolver++ / midpoint / epsilon, solver_order <= 2, plain sigmas are implemented")
+        self.betas = _betas(cfg["beta_schedule"], cfg["beta_start"], cfg["beta_end"], cfg["num_train_timesteps"], cfg["trained_betas"])
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.alpha_t = torch.sqrt(self.alphas_cumprod)
+        self.sigma_t = torch.sqrt(1 - self.alphas_cumprod)
+        self.lambda_t = torch.log(self.alpha_t) - torch.log(self.sigma_t)
+        self.sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.linspace(0, cfg["num_train_timesteps"] - 1, cfg["num_train_timesteps"], dtype=np.float32)[::-1].copy())
+        self.model_outputs = [None] * cfg["solver_order"]
+        self.lower_order_nums = 0
+        self._step_index = None
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def set_timesteps(self, num_inference_steps=None, device=None):
+        c = self.config
+        last = c.num_train_timesteps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, last - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ratio = last // (num_inference_steps + 1)
+            ts = (np.arange(0, num_inference_steps + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64)
+            ts += c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ratio = c.num_train_timesteps / num_inference_steps
+            ts = np.arange(last, 0, -ratio).round().copy().astype(np.int64) - 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported")
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        if c.final_sigmas_type == "sigma_min":
+            sigma_last = ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
+        elif c.final_sigmas_type == "zero":
+            sigma_last = 0
+        else:
+            raise ValueError(f"`final_sigmas_type` must be one of 'zero', or 'sigma_min', but got {c.final_sigmas_type}")
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [sigma_last]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts).to(device=device, dtype=torch.int64)
+        self._ts_host = [int(v) for v in ts]
+        self.num_inference_steps = len(ts)
+        self.model_outputs = [None] * c.solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+
+    @staticmethod
+    def _sigma_to_alpha_sigma_t(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def _init_step_index(self, timestep):
+        t = int(timestep)
+        idx = [k for k, v in enumerate(self._ts_host) if v == t]
+        if not idx:
+            self._step_index = len(self._ts_host) - 1
+        else:
+            self._step_index = idx[1] if len(idx) > 1 else idx[0]
+
+    def step(self, model_output, timestep, sample, generator=None, variance_noise=None, return_dict=True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        c = self.config
+        i, n = self._step_index, len(self._ts_host)
+        lower_order_final = (i == n - 1) and (c.euler_at_final or (c.lower_order_final and n < 15) or c.final_sigmas_type == "zero")
+        lower_order_second = (i == n - 2) and c.lower_order_final and n < 15
+        alpha_s0, sigma_s0 = self._sigma_to_alpha_sigma_t(self.sigmas[i])
+        x0_pred = (sample - sigma_s0 * model_output) / alpha_s0  # convert_model_output: dpmsolver++, epsilon
+        for k in range(c.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = x0_pred
+        sample = sample.to(torch.float32)
+        alpha_t, sigma_t = self._sigma_to_alpha_sigma_t(self.sigmas[i + 1])
+        lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
+        lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = lambda_t - lambda_s0
+        if c.solver_order == 1 or self.lower_order_nums < 1 or lower_order_final:
+            prev = (sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * x0_pred
+        elif c.solver_order == 2 or self.lower_order_nums < 2 or lower_order_second:
+            alpha_s1, sigma_s1 = self._sigma_to_alpha_sigma_t(self.sigmas[i - 1])
+            lambda_s1 = torch.log(alpha_s1) - torch.log(sigma_s1)
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            h_0 = lambda_s0 - lambda_s1
+            r0 = h_0 / h
+            D0, D1 = m0, (1.0 / r0) * (m0 - m1)
+            prev = ((sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * D0
+                    - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1)
+        if self.lower_order_nums < c.solver_order:
+            self.lower_order_nums += 1
+        prev = prev.to(model_output.dtype)
+        self._step_index += 1
+        return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)

@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from ..components import AutoencoderKL, DDPMScheduler, PNDMScheduler, UNet2DConditionModel
+from ..components import AutoencoderKL, DDPMScheduler, DPMSolverMultistepScheduler, PNDMScheduler, UNet2DConditionModel
 from ..components.configuration import FrozenDict
 
 _LOADABLE = {
@@ -22,6 +22,7 @@ _LOADABLE = {
     "AutoencoderKL": AutoencoderKL,
     "PNDMScheduler": PNDMScheduler,
     "DDPMScheduler": DDPMScheduler,
+    "DPMSolverMultistepScheduler": DPMSolverMultistepScheduler,
 }
 
 

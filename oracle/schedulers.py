@@ -151,3 +151,84 @@ class DDPMScheduler:
             var = torch.clamp(b_p / b_t * cur_b, min=1e-20)
             prev = prev + (var ** 0.5) * noise
         return (prev,) if not return_dict else SimpleNamespace(prev_sample=prev)
+
+
+class DPMSolverMultistepScheduler:
+    """diffusers ``DPMSolverMultistepScheduler`` restated for the configuration the reference reaches with
+    ``DPMSolverMultistepScheduler.from_config(pipeline.scheduler.config)``
+    (scripts/inference/experiments/formal_improved.py:195, scripts/stage2/experiments/scheduler_tuning.py:190-201):
+    algorithm ``dpmsolver++``, ``solver_order`` 2, ``midpoint``, epsilon prediction, ``lower_order_final``,
+    ``final_sigmas_type="zero"``, no Karras sigmas.  PARITY UNPINNED (diffusers not installed); pinned by the
+    closed form: with an x0-consistent model the multistep update is exact and the sampler returns x0."""
+
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 solver_order=2, timestep_spacing="leading", steps_offset=1, lower_order_final=True, clip_sample=False):
+        self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                              beta_schedule=beta_schedule, solver_order=solver_order, timestep_spacing=timestep_spacing,
+                              steps_offset=steps_offset, lower_order_final=lower_order_final, clip_sample=clip_sample,
+                              algorithm_type="dpmsolver++", solver_type="midpoint", prediction_type="epsilon",
+                              final_sigmas_type="zero")
+        assert solver_order in (1, 2)
+        self.betas = _betas(self.config)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        c = self.config
+        last = c.num_train_timesteps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, last - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ratio = last // (num_inference_steps + 1)
+            ts = (np.arange(0, num_inference_steps + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + c.steps_offset
+        else:
+            raise NotImplementedError(c.timestep_spacing)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts).to(device)
+        self.num_inference_steps = len(ts)
+        self.model_outputs = [None] * c.solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        if self._step_index is None:
+            idx = (self.timesteps.cpu() == int(timestep)).nonzero()
+            self._step_index = int(idx[1] if len(idx) > 1 else idx[0])
+        i, n = self._step_index, len(self.timesteps)
+        lower_final = i == n - 1  # final_sigmas_type == "zero"
+        lower_second = i == n - 2 and self.config.lower_order_final and n < 15
+        a_s0, s_s0 = self._alpha_sigma(self.sigmas[i])
+        x0 = (sample - s_s0 * model_output) / a_s0  # convert_model_output (dpmsolver++, epsilon)
+        for k in range(self.config.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = x0
+        a_t, s_t = self._alpha_sigma(self.sigmas[i + 1])
+        lam_t, lam_s0 = torch.log(a_t) - torch.log(s_t), torch.log(a_s0) - torch.log(s_s0)
+        h = lam_t - lam_s0
+        if self.config.solver_order == 1 or self.lower_order_nums < 1 or lower_final:
+            prev = (s_t / s_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * x0
+        else:
+            a_s1, s_s1 = self._alpha_sigma(self.sigmas[i - 1])
+            lam_s1 = torch.log(a_s1) - torch.log(s_s1)
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            h_0 = lam_s0 - lam_s1
+            r0 = h_0 / h
+            d0, d1 = m0, (1.0 / r0) * (m0 - m1)
+            prev = (s_t / s_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * d0 - 0.5 * (a_t * (torch.exp(-h) - 1.0)) * d1
+        if self.lower_order_nums < self.config.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        return (prev,) if not return_dict else SimpleNamespace(prev_sample=prev)

@@ -323,3 +323,49 @@ def test_replace_conv_in_matches_reference_recipe():
     assert hu.config.in_channels == 8
     assert torch.equal(hu.state_dict()["conv_in.weight"], w4.repeat(1, 2, 1, 1) * 0.5)  # generate_hdr.py:79-81
     assert torch.equal(hu.state_dict()["conv_in.bias"], b4)
+
+
+def test_dpm_solver_pp_known_answer_and_oracle_agreement():
+    """DPM-Solver++ is exact for an x0-consistent model: with eps = (x - alpha x0)/sigma the sampler must land on x0
+    (sigma_last = 0); product and oracle restatements agree step by step; from_config swap as formal_improved.py:195."""
+    from gm_diffusion.components import DPMSolverMultistepScheduler
+
+    ddpm = DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, clip_sample=False)
+    p = DPMSolverMultistepScheduler.from_config(ddpm.config)
+    assert p.config.timestep_spacing == "leading" and p.config.steps_offset == 1 and p.config.beta_schedule == "scaled_linear"
+    o = OS.DPMSolverMultistepScheduler()
+    for n in (20, 8):
+        p.set_timesteps(n)
+        o.set_timesteps(n)
+        assert torch.equal(p.timesteps, o.timesteps) and torch.equal(p.sigmas, o.sigmas) and len(p.timesteps) == n
+        x0 = torch.full((1, 4, 2, 2), 0.6)
+        noise = torch.full((1, 4, 2, 2), -0.9)
+        a0, s0 = p._sigma_to_alpha_sigma_t(p.sigmas[0])
+        x = a0 * x0 + s0 * noise
+        xo = x.clone()
+        for i, t in enumerate(p.timesteps):
+            a, s_ = p._sigma_to_alpha_sigma_t(p.sigmas[i])
+            eps = (x - a * x0) / s_
+            x = p.step(eps, t, x, return_dict=False)[0]
+            xo = o.step((xo - a * x0) / s_, t, xo, return_dict=False)[0]
+            assert torch.allclose(x, xo, atol=1e-6)
+        assert torch.allclose(x, x0, atol=1e-4)
+    import inspect
+
+    assert "generator" in inspect.signature(p.step).parameters and "eta" not in inspect.signature(p.step).parameters
+    with pytest.raises(NotImplementedError):
+        DPMSolverMultistepScheduler(use_karras_sigmas=True)
+
+
+def test_dual_pipeline_with_dpm_solver(unets):
+    from gm_diffusion.components import DPMSolverMultistepScheduler
+
+    sched = DPMSolverMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                        timestep_spacing="leading")
+    p = dual_pipe(*unets, sched=sched)
+    p.set_progress_bar_config(disable=True)
+    pe, ne, lat = fixtures.make_inputs(1, 8, 8, cross_dim=64)
+    a, b = p(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=64, width=64, num_inference_steps=5,
+             guidance_scale=9.0, eta=0.7, output_type="latent")  # eta is dropped: step() takes none (gm.py:610-625)
+    ra, rb = OP.dual_loop(unets[0], unets[1], OS.DPMSolverMultistepScheduler(), pe, ne, lat, 5, guidance_scale=9.0)
+    assert torch.allclose(a, ra, atol=1e-5) and torch.allclose(b, rb, atol=1e-5)
