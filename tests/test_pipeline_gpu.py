@@ -143,3 +143,23 @@ def test_graph_replay_equals_eager_and_streams():
     pipe.use_hip_graphs, pipe.overlap_streams = False, False
     e = pipe(**kw2)
     assert torch.equal(d[0], e[0]) and torch.equal(d[1], e[1]) and not torch.equal(d[0], a[0])
+
+
+def test_dual_pipeline_dpm_solver_on_device_matches_oracle():
+    """the DPM-Solver++ swap the reference makes (formal_improved.py:195) runs the HIP models through
+    the generic scheduler protocol; fp32 latents must match the oracle loop within the north-star tolerance."""
+    from gm_diffusion.components import DPMSolverMultistepScheduler
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    pipe = _dual_pipe(torch.float32)
+    pipe.scheduler = DPMSolverMultistepScheduler(
+        beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, timestep_spacing="leading")
+    pipe.set_progress_bar_config(disable=True)
+    pe, ne, lat = fixtures.make_inputs(1, 16, 16, cross_dim=64)
+    sdr, gm = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+                   num_inference_steps=8, guidance_scale=7.5, output_type="latent")
+    rs, rg = OP.dual_loop(fixtures.build_unet("tiny", 4), fixtures.build_unet("tiny", 8), OS.DPMSolverMultistepScheduler(),
+                          pe, ne, lat, 8, guidance_scale=7.5)
+    assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
