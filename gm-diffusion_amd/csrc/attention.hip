@@ -16,6 +16,8 @@
 // ds_read_b128 (K) and ds_read_b64 (V^T) fragment reads are bank-conflict free.
 #include "gmd_common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct AttnParams {
@@ -33,7 +35,8 @@ constexpr int VROW = 136;   // bytes per V^T LDS row: 64 keys * 2 B + 8 B pad (c
 constexpr float kNegBig = -1.0e30f;
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+// d <= 40: four waves per SIMD (128 VGPRs), d <= 64: three (<= 168) -- the softmax VALU of one wave hides under the MFMAs of the others
+__global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;         // 16-wide k-steps of Q K^T over d
     constexpr int DT = (D + 31) / 32;         // 32-row tiles of O^T over d
     constexpr int KROW = (2 * DK + 1) * 16;   // bytes per K LDS row: odd number of 16-byte slots
@@ -43,6 +46,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     constexpr int kStageBytes = KV * KROW + DT * 32 * VROW;  // one pipeline stage: K tile [KV][KROW] + V^T tile [DT*32][VROW]
     constexpr int NKC = (KV * DC + 255) / 256;                // 16-byte K chunks staged per thread
     constexpr int NVC = (D * 8 + 255) / 256;                  // 16-byte V^T chunks staged per thread
+    // A spare V^T row (d padded to a multiple of 32) is filled with ones: O^T[D][q] then accumulates the softmax row sum
+    // on the matrix core (from the same bf16 P the numerator uses) and the 32 VALU adds per tile disappear.
+    constexpr bool kRowSumMfma = DT * 32 > D;
+    // A spare k column of the first product (d padded to a multiple of 16) carries the softmax stabiliser through the
+    // matrix core: K[key][D] = 1 and Q[q][D] = -m[q], with Q pre-multiplied by scale*log2(e), so the accumulator IS
+    // log2(p) relative to the running stabiliser m of the PREVIOUS tile and exp2 applies to it directly (no per-score
+    // v_fma).  m moves only when a tile's maximum exceeds it; the output is rescaled after the second product.  A tile
+    // whose scores exceed the lagged stabiliser by more than 2^kLagMax (and always the first tile) takes the classic
+    // path: subtract the tile's own maximum before exp2.  m is kept bf16-representable so the MFMA subtracts exactly
+    // what the rescale assumes.
+    constexpr bool kLagged = kRowSumMfma && DK * 16 > D;
+    constexpr float kLagMax = 20.0f;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -59,11 +74,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         unsigned char* Ks0 = smem + st * kStageBytes;
         unsigned char* Vs0 = Ks0 + KV * KROW;
         if (DK * 16 > D) {
-            for (int i = tid; i < KV; i += 256) *reinterpret_cast<uint4*>(Ks0 + i * KROW + DC * 16) = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < KV; i += 256)
+                *reinterpret_cast<uint4*>(Ks0 + i * KROW + DC * 16) = make_uint4(kLagged ? 0x3F80u : 0u, 0, 0, 0);  // K[key][D] = 1.0
         }
         for (int i = tid; i < (DT * 32 - D) * (VROW / 8); i += 256) {
             const int row = D + i / (VROW / 8), c = i % (VROW / 8);
-            *reinterpret_cast<uint2*>(Vs0 + row * VROW + c * 8) = make_uint2(0, 0);
+            const unsigned fill = (kRowSumMfma && row == D) ? 0x3F803F80u : 0u;  // bf16 1.0 pairs in the row-sum row
+            *reinterpret_cast<uint2*>(Vs0 + row * VROW + c * 8) = make_uint2(fill, fill);
         }
     }
 
@@ -75,6 +92,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (qvalid && d0 + 8 <= D) v = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * p.ldq + d0);
         qf[s] = as_frag(v);
+        if constexpr (kLagged) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)((float)qf[s][j] * p.scale_log2);
+        }
     }
 
     f32x16 ot[DT];
@@ -82,41 +103,58 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) ot[t][i] = 0.f;
-    float m_run = kNegBig, l_run = 0.f;
-    const float c = p.scale_log2;
+    float m_run = kLagged ? 0.f : kNegBig, l_run = 0.f;
+    [[maybe_unused]] int lag_overflow = 0;
+    [[maybe_unused]] auto set_stabiliser = [&](float m_new) {  // m_new must be bf16-representable
+        constexpr int SP = D / 16, HP = (D % 16) / 8;          // fragment / lane half holding column D of Q
+        m_run = m_new;
+        const __bf16 nm = (__bf16)(-m_new);
+        qf[SP < DK ? SP : 0][0] = hh == HP ? nm : qf[SP < DK ? SP : 0][0];
+    };
 
     // register staging of the NEXT tile: issued before the MFMAs of the current tile, written to the other LDS
     // stage after them (one barrier per tile)
     uint4 kreg[NKC], vreg[NVC];
-    auto load_kv = [&](int k0) {
+    // per-thread staging slots are tile-invariant: BYTE offsets of this thread's K / V^T chunks inside a tile, used as the
+    // 32-bit voffset of raw buffer loads (the tile start is the scalar soffset: no 64-bit per-lane addresses).  Rows of K
+    // at or beyond Nk and the slots a thread does not own fall outside the descriptor's range and read as zeros.
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Kb, 0, (int)((((int64_t)p.Nk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Vb, 0, (int)((((int64_t)D - 1) * p.ldvt + (p.Nk + 7) / 8 * 8) * 2), 0x00020000);
+    int kofs[NKC], vofs[NVC];
 #pragma unroll
-        for (int u = 0; u < NKC; ++u) {
-            const int id = tid + 256 * u;
-            const int key = id / DC, ch = id - key * DC;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (id < KV * DC && k0 + key < p.Nk) v = *reinterpret_cast<const uint4*>(Kb + (int64_t)(k0 + key) * p.ldk + ch * 8);
-            kreg[u] = v;
-        }
+    for (int u = 0; u < NKC; ++u) {
+        const int id = tid + 256 * u, key = id / DC;
+        kofs[u] = id < KV * DC ? (key * (int)p.ldk + (id - key * DC) * 8) * 2 : 0x7fffffff;
+    }
+#pragma unroll
+    for (int u = 0; u < NVC; ++u) {
+        const int id = tid + 256 * u;
+        vofs[u] = id < D * 8 ? ((id >> 3) * (int)p.ldvt + (id & 7) * 8) * 2 : 0x7fffffff;
+    }
+    auto as_u4 = [](auto v) { return *reinterpret_cast<uint4*>(&v); };
+    auto load_kv = [&](int k0) {
+        const int ksoff = k0 * (int)p.ldk * 2, vsoff = k0 * 2;
+#pragma unroll
+        for (int u = 0; u < NKC; ++u) kreg[u] = as_u4(__builtin_amdgcn_raw_buffer_load_b128(rsK, kofs[u], ksoff, 0));
+#pragma unroll
+        for (int u = 0; u < NVC; ++u) vreg[u] = as_u4(__builtin_amdgcn_raw_buffer_load_b128(rsV, vofs[u], vsoff, 0));
+        if (k0 + KV <= p.Nk) return;  // full tile (wave-uniform)
+        // last, partial tile: V^T columns of keys >= Nk (row padding, or the next row's keys) are staged as zeros; their
+        // scores are masked to -inf as well
 #pragma unroll
         for (int u = 0; u < NVC; ++u) {
-            const int id = tid + 256 * u;
-            const int d = id >> 3, ch = id & 7;
-            const int key = k0 + ch * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (id < D * 8 && key < p.Nk) {
-                v = *reinterpret_cast<const uint4*>(Vb + (int64_t)d * p.ldvt + key);
-                const int nv = p.Nk - key;  // valid elements in this chunk (>= 1); keys >= Nk are zeroed
-                if (nv < 8) {
-                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+            const int nv = p.Nk - (k0 + ((tid + 256 * u) & 7) * 8);  // valid elements in this chunk
+            if (nv < 8) {
+                unsigned w[4] = {vreg[u].x, vreg[u].y, vreg[u].z, vreg[u].w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (2 * e >= nv) w[e] = 0;
-                        else if (2 * e + 1 >= nv) w[e] &= 0xffffu;
-                    }
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                for (int e = 0; e < 4; ++e) {
+                    if (2 * e >= nv) w[e] = 0;
+                    else if (2 * e + 1 >= nv) w[e] &= 0xffffu;
                 }
+                vreg[u] = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            vreg[u] = v;
         }
     };
     auto store_kv = [&](int st) {
@@ -141,15 +179,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     };
 
     const int ntiles = (p.Nk + KV - 1) / KV;
-    load_kv(0);
-    __syncthreads();  // padding zero-fill visible before the first stage is written around it
-    store_kv(0);
-    __syncthreads();
-    for (int kt = 0; kt < ntiles; ++kt) {
+    // softmax scale inside the loop: the lagged variant folded it into Q
+    const float c = kLagged ? 1.0f : p.scale_log2;
+
+    // one K/V tile.  STAGE is a compile-time constant when the tile loop is unrolled by two (every LDS address of the
+    // fragment reads is then a per-lane base plus an immediate); LAG selects the lagged-stabiliser softmax.
+    auto tile = [&](const int kt, auto stage_c, auto lag_c) {
+        constexpr bool LAG = decltype(lag_c)::value;
+        const int STAGE = stage_c;
         const int k0 = kt * KV;
-        const unsigned char* Ks = smem + (kt & 1) * kStageBytes;
+        const unsigned char* Ks = smem + STAGE * kStageBytes;
         const unsigned char* Vs = Ks + KV * KROW;
-        if (kt + 1 < ntiles) load_kv(k0 + KV);
+        // prefetch of the next tile into registers: at the top for the classic loop; the lagged loop (128-VGPR budget) issues
+        // it after the softmax, where the score registers are dead, and lets the second product hide the latency
+        if constexpr (!LAG) {
+            if (kt + 1 < ntiles) load_kv(k0 + KV);
+        }
 
         // ---- S^T = K Q^T for two 32-key tiles ----
         f32x16 st[2];
@@ -174,34 +219,50 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                 }
         }
         // ---- online softmax (query = lane&31; this half-wave holds 32 of the 64 keys) ----
-        float mx = st[0][0];
+        float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[t][i]);
+        for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[0][i]), st[1][i]);  // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
-        float psum = 0.f;
+        float alpha;
+        if constexpr (LAG) {
+            // st is already log2(p) against the stabiliser of the previous tile: exp2 applies directly.  The stabiliser
+            // then follows the running maximum; this tile was accumulated against the old one, so the output is rescaled
+            // AFTER the second product.
+            lag_overflow |= mx > kLagMax;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(st[t][i] * c - mc);
-                st[t][i] = pv;
-                psum += pv;
+                for (int i = 0; i < 16; ++i) st[t][i] = __builtin_amdgcn_exp2f(st[t][i]);
+            const float m_new = (float)(__bf16)(m_run + fmaxf(mx, 0.f));
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            set_stabiliser(m_new);
+        } else {
+            const float m_new = fmaxf(m_run, mx);
+            alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            const float mc = m_new * c;
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(st[t][i] * c - mc);
+                    st[t][i] = pv;
+                    if constexpr (!kRowSumMfma) psum += pv;
+                }
+            if constexpr (!kRowSumMfma) l_run = l_run * alpha + psum;
+            if (!__all(alpha == 1.0f)) {  // wave-uniform: no running max of this wave moved -> no rescale
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ot[t][i] *= alpha;
             }
-        l_run = l_run * alpha + psum;
-        if (!__all(alpha == 1.0f)) {  // wave-uniform: the running max of every query of this wave is unchanged -> no rescale
-#pragma unroll
-            for (int t = 0; t < DT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) ot[t][i] *= alpha;
         }
         // P^T -> bf16 B fragments: k-step ks = 2 t + s uses registers 8 s .. 8 s + 7 of tile t
         bf16x8 pf[4];
+        if constexpr (LAG) {
+            if (kt + 1 < ntiles) load_kv(k0 + KV);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -226,12 +287,75 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                 ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[dt], 0, 0, 0);
             }
         }
-        if (kt + 1 < ntiles) store_kv((kt + 1) & 1);  // that stage was last read in iteration kt-1
+        if constexpr (LAG) {
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ot[t][i] *= alpha;
+            }
+        }
+        if (kt + 1 < ntiles) store_kv(STAGE ^ 1);  // that stage was last read in iteration kt-1
         __syncthreads();
+    };
+
+    load_kv(0);
+    __syncthreads();  // padding fill visible before the first stage is written around it
+    store_kv(0);
+    __syncthreads();
+    if constexpr (kLagged) {
+        // initial stabiliser: the maximum of the first tile's scores (one extra first product, 1/ntiles of the work)
+        {
+            float mx = kNegBig;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 s0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s0[i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < DK; ++s) {
+                    const bf16x8 kf = as_frag(*reinterpret_cast<const uint4*>(smem + (32 * t + r) * KROW + (2 * s + hh) * 16));
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key < p.Nk) mx = fmaxf(mx, s0[i]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            set_stabiliser((float)(__bf16)mx);
+        }
+        for (int kt = 0; kt < ntiles; ++kt) tile(kt, kt & 1, std::true_type{});
+        // A score more than 2^kLagMax above the lagged stabiliser could overflow exp2: redo the whole block with the
+        // classic (maximum-first) softmax.  Block-wide decision -- every wave takes part in the staging barriers.
+        if (__syncthreads_or(lag_overflow)) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ot[t][i] = 0.f;
+            set_stabiliser(0.f);
+            m_run = kNegBig;
+            load_kv(0);
+            store_kv(0);
+            __syncthreads();
+            for (int kt = 0; kt < ntiles; ++kt) tile(kt, kt & 1, std::false_type{});
+        }
+    } else {
+        for (int kt = 0; kt < ntiles; kt += 2) {
+            tile(kt, std::integral_constant<int, 0>{}, std::false_type{});
+            if (kt + 1 < ntiles) tile(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        }
     }
 
     // ---- normalise and store: lane owns query q, registers hold d = 32 dt + 8 g + 4 hh + i ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (kRowSumMfma) {
+        // row D of O^T: tile D/32, register 4*((D%32)/8) of the lanes with hh == 0 (D is a multiple of 8)
+        l_tot = __shfl(ot[D / 32][4 * ((D % 32) / 8)], r, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_tot;
     if (qvalid) {
         bf16_t* Ob = p.O + (int64_t)b * p.sO + (int64_t)q * p.ldo + (int64_t)head * D;
@@ -279,6 +403,7 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
     GMD_REQUIRE(gmd_aligned16(Q) && gmd_aligned16(K) && gmd_aligned16(Vt) && gmd_aligned16(O), "gmd_attention: pointers must be 16-byte aligned");
     GMD_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "gmd_attention: leading dimensions must be multiples of 8 (ldo: 4)");
     GMD_REQUIRE(strideQ % 8 == 0 && strideK % 8 == 0 && strideVt % 8 == 0 && strideO % 4 == 0, "gmd_attention: batch strides must be multiples of 8");
+    GMD_REQUIRE((int64_t)Nk * ldk < (1ll << 30) && (int64_t)D * ldvt < (1ll << 30), "gmd_attention: K / V^T slab of one head exceeds 2 GiB");
     GMD_REQUIRE(ldvt >= ((Nk + 7) / 8) * 8, "gmd_attention: ldvt=%lld must cover Nk=%d rounded up to 8", (long long)ldvt, Nk);
     GMD_REQUIRE(ldq >= (int64_t)H * D && ldk >= (int64_t)H * D && ldo >= (int64_t)H * D, "gmd_attention: row stride smaller than H*D");
     AttnParams p;

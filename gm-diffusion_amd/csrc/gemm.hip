@@ -782,7 +782,9 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
     int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
     const int nk = K / BK;
     if (batch == 1 && tiles < 160 && nk >= 24 && !pair_tiles) {  // K >= 1536: the slab reduction (a second launch) must pay for itself
-        int ks = (int)((384 + tiles - 1) / tiles);
+        // whole waves of blocks: 512 (two per CU) when the tile grid is at least a quarter of the chip, else 256 (the
+        // fp32 slab traffic of more slices costs more than the second resident block buys) -- measured, tools/bench_gemm.py
+        int ks = (int)(((tiles >= 64 ? 512 : 256) + tiles / 2) / tiles);
         if (ks > nk / 8) ks = nk / 8;  // at least 8 K steps (512 channels) per slice
         if (ks > 16) ks = 16;
         if (ks > 1 && (int64_t)ks * M * N * (int64_t)sizeof(float) <= ws_bytes) pl.ksplit = ks;

@@ -140,6 +140,10 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                 g_sdr = self.unet.graphed_forward((2 if do_cfg else 1) * latents.shape[0], h, w, ctx)
                 g_gm = self.gm_unet.graphed_forward(latents.shape[0], h, w, gm_ctx)
             gm_stream.wait_stream(sdr_stream)
+            if gm_stream is not sdr_stream:
+                # allocated on the caller's stream, consumed (and released) by step 0 on the GM stream: without this the
+                # allocator may hand the block to the SDR stream's step 1 while GM step 0 still reads it
+                gm_latents.record_stream(gm_stream)
 
         with self.progress_bar(total=num_inference_steps) as progress_bar:
             for i, t in enumerate(timesteps):

@@ -379,21 +379,42 @@ def test_attention_bf16(D, Nq, Nk):
     assert max_err(got.float(), ref) < 6e-2
 
 
-def test_attention_rescale_branch_spiked_keys():
-    """Force the running max to jump in a later tile (rare online-softmax branch)."""
+@pytest.mark.parametrize("spike", [1.5, 3.0, 8.0])
+def test_attention_rescale_branch_spiked_keys(spike):
+    """Force the running max to jump in a later tile: 1.5 -> the lagged-stabiliser rescale (d=40 kernel), 3.0 / 8.0 ->
+    a jump of more than 2^20, which must take the classic-softmax fallback instead of overflowing."""
     o = ops()
     heads, B, D, N = 1, 1, 40, 320
     g = torch.Generator().manual_seed(77)
     q = torch.randn(B, N, D, generator=g)
     k = torch.randn(B, N, D, generator=g) * 0.3
     v = torch.randn(B, N, D, generator=g)
-    k[0, 200] = q[0, 5] * 3.0   # query 5 sees a huge score at key 200 (4th tile)
-    k[0, 310] = q[0, 100] * 4.0
+    k[0, 200] = q[0, 5] * spike   # query 5 sees a huge score at key 200 (4th tile)
+    k[0, 310] = q[0, 100] * (spike + 1.0)
     q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
     vt = v.transpose(1, 2).contiguous()
     got = o.attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads, N, D ** -0.5)
     ref = _attn_ref(q, k, v, heads, D ** -0.5)
+    assert torch.isfinite(got.float()).all()
     assert max_err(got.float(), ref) < 6e-2 and rel_err(got.float(), ref) < 1.2e-2
+
+
+@pytest.mark.parametrize("D", [40, 80])
+def test_attention_large_and_negative_logits(D):
+    """Scores far from zero in both directions: all-negative rows (the first-tile stabiliser must be the tile maximum, not
+    zero) and logits of magnitude ~100."""
+    o = ops()
+    heads, B, N = 2, 1, 200
+    g = torch.Generator().manual_seed(D)
+    base = torch.randn(1, 1, heads * D, generator=g)
+    q = (base * 4.0 + 0.3 * torch.randn(B, N, heads * D, generator=g))
+    k = (-base * 4.0 + 0.3 * torch.randn(B, N, heads * D, generator=g))   # q.k ~ -16 |base|^2: every score << 0
+    v = torch.randn(B, N, heads * D, generator=g)
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    got = o.attention(q.to(DEV), k.to(DEV), v.transpose(1, 2).contiguous().to(DEV), heads, N, D ** -0.5)
+    ref = _attn_ref(q, k, v, heads, D ** -0.5)
+    assert torch.isfinite(got.float()).all()
+    assert max_err(got.float(), ref) < 8e-2 and rel_err(got.float(), ref) < 3e-2
 
 
 def test_attention_fused_qk_buffer():

@@ -20,12 +20,14 @@ CONVS = [  # B, H, W, Cin, Cout
 GEMMS = [  # M, N, K
     (32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560),
     (2048, 1280, 1280), (2048, 10240, 1280), (2048, 1280, 5120), (512, 1280, 1280), (16384, 320, 320), (8, 1280, 1280),
+    (4096, 640, 640), (1024, 1280, 1280), (32768, 640, 320), (8192, 1280, 640), (16384, 320, 1280), (4096, 640, 2560),
 ]
 
 
-def timeit(fn, reps=20):
+def timeit(fn, reps=100):
     fn(); fn()
     torch.cuda.synchronize()
+    torch.cuda._sleep(int(1e7))  # ~0.1 s device-side lead so the host is ahead of the GPU (launch latency not counted)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -37,6 +39,11 @@ def timeit(fn, reps=20):
 
 def main():
     g = torch.Generator().manual_seed(0)
+    global CONVS, GEMMS
+    if "--gemm-only" in sys.argv:
+        CONVS = []
+    if "--conv-only" in sys.argv:
+        GEMMS = []
     print("variant:", os.environ.get("GMD_GEMM_FORCE", "heuristic"))
     tot = 0.0
     for B, H, W, ci, co in CONVS:
