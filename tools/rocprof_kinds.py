@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Fold a rocprofv3 --kernel-trace CSV into the per-kind table bench.py prints (conv3x3 = implicit-GEMM conv kernel plus the
+split-K reduction that follows it; gemm_nt likewise; attention), so the rocprof durations can be compared with the
+HIP-event durations of bench.py's instrumented step.  Usage: rocprof_kinds.py <kernel_trace.csv>"""
+import collections, csv, re, sys
+
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+agg = collections.OrderedDict()
+def add(kind, ns):
+    a = agg.setdefault(kind, [0, 0])
+    a[0] += 1; a[1] += ns
+last_kind = None
+for s, e, name in rows:
+    d = e - s
+    if "splitk_reduce" in name:
+        if last_kind:  # belongs to the GEMM / conv launch it completes: add time, not a launch
+            agg[last_kind][1] += d
+        continue
+    if "gemm_ring_kernel<true" in name or "gemm_bf16_kernel<true" in name or "gemm_f32_kernel<true" in name:
+        last_kind = "conv3x3"
+    elif "gemm_ring_kernel<false" in name or "gemm_bf16_kernel<false" in name or "gemm_f32_kernel<false" in name:
+        last_kind = "gemm_nt"
+    elif "attn_fwd_kernel" in name:
+        last_kind = "attention"
+    else:
+        last_kind = None
+        m = re.search(r"(?:::)?(\w+)\s*(?:<|\()", name.replace("void ", "").replace("(anonymous namespace)::", ""))
+        add("other:" + (m.group(1) if m else name[:40]), d)
+        continue
+    add(last_kind, d)
+tot = sum(v[1] for v in agg.values())
+print(f"{'kind':48s} {'launches':>9s} {'total_ms':>10s} {'avg_us':>8s} {'share':>6s}")
+for k, (n, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"{k:48s} {n:9d} {ns / 1e6:10.3f} {ns / n / 1e3:8.2f} {ns / tot:6.3f}")
