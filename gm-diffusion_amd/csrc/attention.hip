@@ -34,7 +34,7 @@ constexpr int KV = 64;      // keys per tile
 constexpr int VROW = 136;   // bytes per V^T LDS row: 64 keys * 2 B + 8 B pad (conflict-free b64 reads)
 constexpr float kNegBig = -1.0e30f;
 
-template <int D>
+template <int D, bool CAUSAL>
 // d <= 40: four waves per SIMD (128 VGPRs), d <= 64: three (<= 168) -- the softmax VALU of one wave hides under the MFMAs of the others
 __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;         // 16-wide k-steps of Q K^T over d
@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
         }
     };
 
-    const int ntiles = (p.Nk + KV - 1) / KV;
+    // CAUSAL (query q attends keys 0..q, Nq == Nk): key tiles entirely above the diagonal of this block's last query are
+    // never visited (block-uniform bound)
+    const int ntiles = CAUSAL ? min((p.Nk + KV - 1) / KV, (min((int)blockIdx.x * 128 + 127, p.Nq - 1)) / KV + 1) : (p.Nk + KV - 1) / KV;
     // softmax scale inside the loop: the lagged variant folded it into Q
     const float c = kLagged ? 1.0f : p.scale_log2;
 
@@ -216,6 +218,15 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
                 for (int i = 0; i < 16; ++i) {
                     const int key = k0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
                     if (key >= p.Nk) st[t][i] = kNegBig;
+                }
+        }
+        if (CAUSAL && k0 + KV - 1 > (int)blockIdx.x * 128 + wid * 32) {  // the tile reaches above this wave's first query
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = k0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key > q) st[t][i] = kNegBig;
                 }
         }
         // ---- online softmax (query = lane&31; this half-wave holds 32 of the 64 keys) ----
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    if (key < p.Nk) mx = fmaxf(mx, s0[i]);
+                    if (key < p.Nk && !(CAUSAL && key > q)) mx = fmaxf(mx, s0[i]);
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -374,12 +385,12 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
     }
 }
 
-template <int D>
+template <int D, bool CAUSAL = false>
 int launch_attn(const AttnParams& p, int B, int H, hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DT = (D + 31) / 32;
     const size_t smem = 2 * ((size_t)KV * (2 * DK + 1) * 16 + (size_t)DT * 32 * VROW);  // two pipeline stages
     dim3 grid((p.Nq + 127) / 128, H, B);
-    attn_fwd_kernel<D><<<grid, 256, smem, s>>>(p);
+    attn_fwd_kernel<D, CAUSAL><<<grid, 256, smem, s>>>(p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gmd_set_error("gmd_attention: launch failed: %s", hipGetErrorString(e));
@@ -392,7 +403,7 @@ int launch_attn(const AttnParams& p, int B, int H, hipStream_t s) {
 
 extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void* O, int dtype, int B, int H, int D, int Nq,
                              int Nk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t strideQ, int64_t strideK,
-                             int64_t strideVt, int64_t strideO, float scale, gmd_stream_t stream) {
+                             int64_t strideVt, int64_t strideO, float scale, int causal, gmd_stream_t stream) {
     if (dtype != GMD_BF16) {
         gmd_set_error("gmd_attention: only GMD_BF16 is implemented (the F32 parity path composes gmd_gemm_nt + gmd_softmax_rows)");
         return GMD_ERR_UNSUPPORTED;
@@ -412,6 +423,13 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
     p.sQ = strideQ; p.sK = strideK; p.sVt = strideVt; p.sO = strideO;
     p.scale_log2 = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
+    if (causal) {  // the text encoder's mask; instantiated for its head dims (CLIP ViT-L/14: 64)
+        GMD_REQUIRE(Nq == Nk, "gmd_attention: the causal mask needs Nq == Nk");
+        if (D == 64) return launch_attn<64, true>(p, B, H, s);
+        if (D == 32) return launch_attn<32, true>(p, B, H, s);
+        gmd_set_error("gmd_attention: causal attention is instantiated for head dims 32 and 64 only (got %d)", D);
+        return GMD_ERR_UNSUPPORTED;
+    }
     switch (D) {
         case 32: return launch_attn<32>(p, B, H, s);
         case 40: return launch_attn<40>(p, B, H, s);

@@ -63,6 +63,22 @@ __global__ __launch_bounds__(kThreads) void cast_kernel(const TI* __restrict__ i
         Elem<TO>::st(out + i, Elem<TI>::ld(in + i));
 }
 
+// out[r, c] = table[ids[r], c] + pos[r % T, c]: one row per (batch, token); an id outside [0, vocab) reads row 0 (the host
+// front end rejects such ids before the launch -- this only keeps a wild pointer impossible)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void embedding_kernel(const int32_t* __restrict__ ids, const T* __restrict__ table,
+                                                             const T* __restrict__ pos, T* __restrict__ out, int64_t rows, int Tn, int C,
+                                                             int vocab) {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        int id = ids[r];
+        if (id < 0 || id >= vocab) id = 0;
+        Elem<T>::st(out + i, Elem<T>::ld(table + (int64_t)id * C + c) + Elem<T>::ld(pos + (int64_t)(r % Tn) * C + c));
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t g = (n + kThreads - 1) / kThreads;
     if (g > 256 * 16) g = 256 * 16;
@@ -124,6 +140,23 @@ int gmd_concat_channels(const void* A, int Ca, const void* Bm, int Cb, void* out
         GMD_REQUIRE(false, "gmd_concat_channels: bad dtype %d", dtype);
     }
     GMD_CHECK_LAUNCH("gmd_concat_channels");
+    return GMD_OK;
+}
+
+int gmd_embedding_lookup(const int32_t* ids, const void* table, const void* pos, void* out, int dtype, int64_t rows, int T, int C,
+                         int vocab, gmd_stream_t stream) {
+    GMD_REQUIRE(rows >= 0 && T > 0 && C > 0 && vocab > 0, "gmd_embedding_lookup: bad shape rows=%lld T=%d C=%d vocab=%d", (long long)rows, T, C, vocab);
+    if (rows == 0) return GMD_OK;
+    GMD_REQUIRE(ids && table && pos && out, "gmd_embedding_lookup: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(rows * C);
+    if (dtype == GMD_BF16)
+        embedding_kernel<bf16_t><<<grid, kThreads, 0, s>>>(ids, (const bf16_t*)table, (const bf16_t*)pos, (bf16_t*)out, rows, T, C, vocab);
+    else if (dtype == GMD_F32)
+        embedding_kernel<float><<<grid, kThreads, 0, s>>>(ids, (const float*)table, (const float*)pos, (float*)out, rows, T, C, vocab);
+    else
+        GMD_REQUIRE(false, "gmd_embedding_lookup: bad dtype %d", dtype);
+    GMD_CHECK_LAUNCH("gmd_embedding_lookup");
     return GMD_OK;
 }
 

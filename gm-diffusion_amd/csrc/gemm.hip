@@ -87,7 +87,11 @@ __device__ __forceinline__ int64_t a_offset(const GemmParams& p, const RowCtx& r
     return (((int64_t)r.b * p.Hin + iy) * p.Win + ix) * p.Cin + c0;
 }
 
-__device__ __forceinline__ float apply_act(float v, int act) { return act == GMD_ACT_SILU ? silu_f(v) : v; }
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == GMD_ACT_SILU) return silu_f(v);
+    if (act == GMD_ACT_QUICK_GELU) return v / (1.0f + __expf(-1.702f * v));
+    return v;
+}
 
 // Fused epilogue for 8 consecutive columns n..n+7 of row m (bf16 activations): alpha, bias, per-group row
 // bias, residual, activation, then a 16-byte store (scalar stores on ragged / unaligned edges).
@@ -897,7 +901,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     GMD_REQUIRE(rowbias == nullptr || rows_per_group > 0, "gmd_gemm_nt: rows_per_group must be positive");
     GMD_REQUIRE(residual == nullptr || (ldr >= N && gmd_aligned16(residual)), "gmd_gemm_nt: bad residual");
     GMD_REQUIRE(residual == nullptr || out_dtype == dtype || dtype == GMD_F32, "gmd_gemm_nt: residual needs out_dtype == dtype");
-    GMD_REQUIRE(act == GMD_ACT_NONE || act == GMD_ACT_SILU || act == GMD_ACT_GEGLU, "gmd_gemm_nt: bad act %d", act);
+    GMD_REQUIRE(act == GMD_ACT_NONE || act == GMD_ACT_SILU || act == GMD_ACT_GEGLU || act == GMD_ACT_QUICK_GELU, "gmd_gemm_nt: bad act %d", act);
     if (act == GMD_ACT_GEGLU) {
         GMD_REQUIRE(dtype == GMD_BF16 && out_dtype == GMD_BF16, "gmd_gemm_nt: GEGLU epilogue is implemented for bf16 only");
         GMD_REQUIRE(N % 32 == 0 && ldc >= N / 2 && ldc % 4 == 0 && strideC % 4 == 0, "gmd_gemm_nt: GEGLU needs N %% 32 == 0 and ldc >= N/2");

@@ -262,9 +262,11 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const T* __restrict
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, T* __restrict__ P,
-                                                                int64_t ldp, int cols, float scale) {
+                                                                int64_t ldp, int cols_all, float scale, int causal_nq) {
     __shared__ float red[kThreads / 64];
     const int64_t row = blockIdx.x;
+    // causal rows attend columns 0 .. (row % Nq) only; the rest of the row is written as zeros
+    const int cols = causal_nq > 0 ? min(cols_all, (int)(row % causal_nq) + 1) : cols_all;
     const float* s = S + row * lds_;
     T* p = P + row * ldp;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -392,16 +394,17 @@ int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C, const 
 }
 
 int gmd_softmax_rows(const float* S, int64_t lds_, void* P, int out_dtype, int64_t ldp, int64_t rows, int cols, float scale,
-                     gmd_stream_t stream) {
+                     int causal_nq, gmd_stream_t stream) {
+    GMD_REQUIRE(causal_nq >= 0, "gmd_softmax_rows: bad causal_nq");
     GMD_REQUIRE(rows >= 0 && cols > 0 && lds_ >= cols && ldp >= cols, "gmd_softmax_rows: bad shape");
     if (rows == 0) return GMD_OK;
     GMD_REQUIRE(S && P, "gmd_softmax_rows: null pointer");
     GMD_REQUIRE(rows < (1LL << 31), "gmd_softmax_rows: too many rows");
     hipStream_t s = (hipStream_t)stream;
     if (out_dtype == GMD_BF16)
-        softmax_rows_kernel<bf16_t><<<(int)rows, kThreads, 0, s>>>(S, lds_, (bf16_t*)P, ldp, cols, scale);
+        softmax_rows_kernel<bf16_t><<<(int)rows, kThreads, 0, s>>>(S, lds_, (bf16_t*)P, ldp, cols, scale, causal_nq);
     else if (out_dtype == GMD_F32)
-        softmax_rows_kernel<float><<<(int)rows, kThreads, 0, s>>>(S, lds_, (float*)P, ldp, cols, scale);
+        softmax_rows_kernel<float><<<(int)rows, kThreads, 0, s>>>(S, lds_, (float*)P, ldp, cols, scale, causal_nq);
     else
         GMD_REQUIRE(false, "gmd_softmax_rows: bad dtype %d", out_dtype);
     GMD_CHECK_LAUNCH("gmd_softmax_rows");

@@ -14,10 +14,10 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GMD_F32, GMD_BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
@@ -39,8 +39,8 @@ SIGNATURES = {
     "gmd_unpack_nchw": [P, I, L, I, I, L, P, P],
     "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, L, P],
     "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, L, P, P, L, P],
-    "gmd_attention": [P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, P],
-    "gmd_softmax_rows": [P, L, P, I, L, L, I, F, P],
+    "gmd_attention": [P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],
+    "gmd_softmax_rows": [P, L, P, I, L, L, I, F, I, P],
     "gmd_groupnorm_nsplit": [L],
     "gmd_groupnorm_stats": [P, I, I, L, I, I, F, P, P, P, P, P],
     "gmd_groupnorm_apply": [P, P, I, I, L, I, P, I, P],
@@ -49,6 +49,7 @@ SIGNATURES = {
     "gmd_geglu": [P, P, I, L, I, P],
     "gmd_timestep_embedding": [P, P, I, I, I, I, F, P],
     "gmd_concat_channels": [P, I, P, I, P, I, L, P],
+    "gmd_embedding_lookup": [P, P, P, P, I, L, I, I, I, P],
     "gmd_cast": [P, I, P, I, L, P],
 }
 _RESTYPES = {"gmd_last_error": c_char_p}

@@ -144,7 +144,7 @@ class _HipModule(ConfigMixin):
         return self._f32(self._raw[key + ".weight"]), self._f32(self._raw[key + ".bias"])
 
 
-def composed_attention(q, q_col, ldq, k, k_col, ldk, vt, B, H, d, nq, nk, scale, dtype):
+def composed_attention(q, q_col, ldq, k, k_col, ldk, vt, B, H, d, nq, nk, scale, dtype, causal=False):
     """Attention as GEMM -> row softmax -> GEMM (float32 parity path and the d=512 VAE block).
     q/k: buffers with rows of ldq/ldk elements, head h at columns q_col + h*d; vt: [B, H*d, ldvt] with
     zero-filled columns >= nk.  Returns [B, nq, H*d]."""
@@ -159,7 +159,7 @@ def composed_attention(q, q_col, ldq, k, k_col, ldk, vt, B, H, d, nq, nk, scale,
     for b in range(B):
         ops.gemm_raw(q.data_ptr() + (b * nq * ldq + q_col) * es, k.data_ptr() + (b * nk * ldk + k_col) * es, s.data_ptr(),
                      dtype, torch.float32, nq, nk, d, ldq, ldk, nkp, batch=H, sA=d, sW=d, sC=nq * nkp)
-        p = ops.softmax_rows(s, nk, scale, dtype, ldp=nkp)
+        p = ops.softmax_rows(s, nk, scale, dtype, ldp=nkp, causal_nq=nq if causal else 0)
         ops.gemm_raw(p.data_ptr(), vt.data_ptr() + b * H * d * ldvt * es, out.data_ptr() + b * nq * H * d * es,
                      dtype, dtype, nq, d, nkp, nkp, ldvt, H * d, batch=H, sA=nq * nkp, sW=d * ldvt, sC=d)
     return out

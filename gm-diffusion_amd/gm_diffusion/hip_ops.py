@@ -15,10 +15,10 @@ from __future__ import annotations
 import torch
 
 from . import profiling
-from ._native import ACT_GEGLU, ACT_NONE, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
+from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
+    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
     "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "groupnorm_split", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
@@ -167,7 +167,7 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     return y, ho, wo
 
 
-def attention(q, k, vt, heads, nk, scale, k_col=0):
+def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False):
     """q: [B, Nq, ldq] with Q in columns [0, H*D); k: [B, Nk, ldk] with K in columns [k_col, k_col+H*D)
     (q and k may be the same fused-projection buffer); vt: [B, H*D, ldvt] (V transposed, keys contiguous)."""
     _dev(q, k, vt)
@@ -183,20 +183,20 @@ def attention(q, k, vt, heads, nk, scale, k_col=0):
     t0 = tm.begin() if tm else None
     check(lib().gmd_attention(_ptr(q), _ptr(k) + k_col * k.element_size(), _ptr(vt), _ptr(o), dtype_code(q.dtype), B, heads, d,
                               nq, nk, ldq, ldk, vt.shape[2], hd, nq * ldq, k.shape[1] * ldk, hd * vt.shape[2], nq * hd,
-                              float(scale), _stream()), "gmd_attention")
+                              float(scale), int(bool(causal)), _stream()), "gmd_attention")
     if tm:  # QK^T + PV, algorithmic head dim (padding not counted)
         tm.end("attention", 4.0 * B * nq * nk * hd, (2 * B * nq * hd + 2 * B * nk * hd) * 2, t0)
     return o
 
 
-def softmax_rows(s, cols, scale, out_dtype, ldp=None):
+def softmax_rows(s, cols, scale, out_dtype, ldp=None, causal_nq=0):
     _dev(s)
     _f32(s, "softmax_rows input")
     lds_ = s.shape[-1]
     rows = s.numel() // lds_
     ldp = ldp or lds_
     p = torch.empty(s.shape[:-1] + (ldp,), dtype=out_dtype, device=s.device)
-    check(lib().gmd_softmax_rows(_ptr(s), lds_, _ptr(p), dtype_code(out_dtype), ldp, rows, cols, float(scale), _stream()),
+    check(lib().gmd_softmax_rows(_ptr(s), lds_, _ptr(p), dtype_code(out_dtype), ldp, rows, cols, float(scale), int(causal_nq), _stream()),
           "gmd_softmax_rows")
     return p
 
@@ -287,6 +287,19 @@ def concat_channels(a, b):
     out = torch.empty(a.shape[:-1] + (ca + cb,), dtype=a.dtype, device=a.device)
     check(lib().gmd_concat_channels(_ptr(a), ca, _ptr(b), cb, _ptr(out), dtype_code(a.dtype), rows, _stream()),
           "gmd_concat_channels")
+    return out
+
+
+def embedding_lookup(ids, table, pos):
+    """ids: integer [B, T] on the device; table [vocab, C], pos [>=T, C] -> [B, T, C] = table[ids] + pos[:T]."""
+    _dev(ids, table, pos)
+    if table.dtype != pos.dtype or table.shape[1] != pos.shape[1] or pos.shape[0] < ids.shape[1]:
+        raise HipExtensionError("embedding_lookup: table / position shapes or dtypes inconsistent")
+    B, T = ids.shape
+    ids32 = ids.to(torch.int32).contiguous()
+    out = torch.empty((B, T, table.shape[1]), dtype=table.dtype, device=table.device)
+    check(lib().gmd_embedding_lookup(_ptr(ids32), _ptr(table), _ptr(pos), _ptr(out), dtype_code(table.dtype), B * T, T, table.shape[1],
+                                     table.shape[0], _stream()), "gmd_embedding_lookup")
     return out
 
 

@@ -14,12 +14,13 @@ import os
 
 import torch
 
-from ..components import AutoencoderKL, DDPMScheduler, DPMSolverMultistepScheduler, PNDMScheduler, UNet2DConditionModel
+from ..components import AutoencoderKL, CLIPTextModel, DDPMScheduler, DPMSolverMultistepScheduler, PNDMScheduler, UNet2DConditionModel
 from ..components.configuration import FrozenDict
 
 _LOADABLE = {
     "UNet2DConditionModel": UNet2DConditionModel,
     "AutoencoderKL": AutoencoderKL,
+    "CLIPTextModel": CLIPTextModel,  # model_index.json lists it under "transformers": the HIP implementation takes over
     "PNDMScheduler": PNDMScheduler,
     "DDPMScheduler": DDPMScheduler,
     "DPMSolverMultistepScheduler": DPMSolverMultistepScheduler,

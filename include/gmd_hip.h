@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 2
+#define GMD_ABI_VERSION 3
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -44,6 +44,7 @@ extern "C" {
 #define GMD_ACT_NONE 0
 #define GMD_ACT_SILU 1
 #define GMD_ACT_GEGLU 2 /* bf16 only: W rows interleaved in 16-row [value|gate] groups; writes [M, N/2] = h * gelu_erf(g) */
+#define GMD_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x): CLIP text encoder MLP */
 
 typedef void* gmd_stream_t;
 
@@ -172,12 +173,15 @@ int gmd_attention(const void* Q, const void* K, const void* Vt, void* O, int dty
                   int B, int H, int D, int Nq, int Nk,
                   int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
                   int64_t strideQ, int64_t strideK, int64_t strideVt, int64_t strideO,
-                  float scale, gmd_stream_t stream);
+                  float scale, int causal, gmd_stream_t stream);
+/* causal != 0 (needs Nq == Nk): query q attends keys 0..q only -- the CLIP text encoder's mask
+ * (transformers CLIPTextModel, used through stable_diffusion_gm.py:398-439). */
 
 /* row softmax: P[r, :cols] = softmax(scale * S[r, :cols]); S float32 ld lds, P out_dtype ld ldp;
- * columns cols..ldp-1 of P are zero-filled. */
+ * columns cols..ldp-1 of P are zero-filled.  causal_nq > 0: row r belongs to query r % causal_nq and
+ * columns beyond that query get probability 0. */
 int gmd_softmax_rows(const float* S, int64_t lds, void* P, int out_dtype, int64_t ldp,
-                     int64_t rows, int cols, float scale, gmd_stream_t stream);
+                     int64_t rows, int cols, float scale, int causal_nq, gmd_stream_t stream);
 
 /* GroupNorm statistics over channels-last X [B,HW,C] -> per (b,c) affine
  * scale_shift[b][c] = {rstd*gamma[c], beta[c]-mean*rstd*gamma[c]}.
@@ -206,6 +210,11 @@ int gmd_timestep_embedding(const float* t_dev, void* out, int dtype, int B, int 
 /* out[r, :Ca] = A[r], out[r, Ca:] = Bm[r]  (skip-connection concat, channels-last) */
 int gmd_concat_channels(const void* A, int Ca, const void* Bm, int Cb, void* out, int dtype,
                         int64_t rows, gmd_stream_t stream);
+/* out[r, :] = table[ids[r], :] + pos[r % T, :]  (token + position embedding of the CLIP text encoder,
+ * stable_diffusion_gm.py:398-439); ids int32 in [0, vocab) -- out-of-range ids are an error the HOST must
+ * exclude (checked there), rows = B*T. */
+int gmd_embedding_lookup(const int32_t* ids, const void* table, const void* pos, void* out, int dtype,
+                         int64_t rows, int T, int C, int vocab, gmd_stream_t stream);
 /* elementwise cast between F32 and BF16 */
 int gmd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, gmd_stream_t stream);
 

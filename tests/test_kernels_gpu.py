@@ -485,3 +485,55 @@ def test_rgbe_encode_bit_exact_and_file(tmp_path):
     head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 37 +X 53\n"
     assert raw.startswith(head) and len(raw) == len(head) + 37 * 53 * 4
     assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(37, 53, 4), got)
+
+
+@pytest.mark.parametrize("D,N", [(64, 77), (32, 77), (64, 200)])
+def test_attention_causal(D, N):
+    """Causal mask of the CLIP text encoder (gmd_attention causal=1), incl. a ragged last tile and multi-tile rows."""
+    o = ops()
+    heads, B = 3, 2
+    C = heads * D
+    g = torch.Generator().manual_seed(D + N)
+    q = torch.randn(B, N, C, generator=g).bfloat16()
+    k = torch.randn(B, N, C, generator=g).bfloat16()
+    v = torch.randn(B, N, C, generator=g).bfloat16()
+    ld = (N + 7) // 8 * 8
+    vt = torch.full((B, C, ld), float("nan")).bfloat16()
+    vt[:, :, :N] = v.transpose(1, 2)
+    got = o.attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads, N, D ** -0.5, causal=True)
+    qf, kf, vf = [t.float().view(B, N, heads, D).transpose(1, 2) for t in (q, k, v)]
+    s = qf @ kf.transpose(-1, -2) * D ** -0.5 + torch.full((N, N), float("-inf")).triu(1)
+    ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B, N, C)
+    assert torch.isfinite(got.float()).all()
+    assert rel_err(got.float(), ref) < 1.2e-2 and max_err(got.float(), ref) < 6e-2
+
+
+def test_attention_causal_unsupported_head_dim_fails_loudly():
+    o = ops()
+    q = torch.zeros(1, 16, 40, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros(1, 40, 16, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(Exception, match="causal"):
+        o.attention(q, q, vt, 1, 16, 1.0, causal=True)
+
+
+def test_softmax_rows_causal_embedding_and_quick_gelu():
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(2, 5, 8, generator=g)           # rows = (head, query) with Nq = 5
+    p = o.softmax_rows(s.to(DEV), 5, 0.7, torch.float32, ldp=8, causal_nq=5).cpu()
+    m = (s[..., :5] * 0.7) + torch.full((5, 5), float("-inf")).triu(1)
+    assert torch.allclose(p[..., :5], torch.softmax(m, -1), atol=1e-6) and float(p[..., 5:].abs().max()) == 0.0
+    table, pos = torch.randn(50, 16, generator=g), torch.randn(7, 16, generator=g)
+    ids = torch.randint(0, 50, (3, 7), generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        e = o.embedding_lookup(ids.to(DEV), table.to(DEV, dt), pos.to(DEV, dt)).float().cpu()
+        assert torch.allclose(e, table.to(dt).float()[ids] + pos.to(dt).float()[None], atol=2e-2 if dt == torch.bfloat16 else 0)
+    x = torch.randn(70, 64, generator=g)
+    w = torch.randn(96, 64, generator=g) / 8
+    b = torch.randn(96, generator=g)
+    z = x @ w.T + b
+    ref = z * torch.sigmoid(1.702 * z)
+    got = o.gemm_nt(x.to(DEV), w.to(DEV), bias=b.to(DEV), act=o.ACT_QUICK_GELU).cpu()
+    assert rel_err(got, ref) < 1e-5
+    gb = o.gemm_nt(x.bfloat16().to(DEV), w.bfloat16().to(DEV), bias=b.to(DEV), act=o.ACT_QUICK_GELU).float().cpu()
+    assert rel_err(gb, ref) < 2e-2

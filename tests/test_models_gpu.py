@@ -115,3 +115,40 @@ def test_models_refuse_cpu():
     m.load_state_dict(ou.state_dict())
     with pytest.raises(HipExtensionError):
         m(torch.zeros(1, 4, 8, 8), 1, encoder_hidden_states=torch.zeros(1, 77, 64))
+
+
+@pytest.mark.parametrize("which,dtype,tol", [("tiny", torch.float32, 3e-5), ("tiny", torch.bfloat16, 4e-2),
+                                             ("clip_l", torch.float32, 5e-5), ("clip_l", torch.bfloat16, 4e-2)])
+def test_clip_text_encoder_matches_oracle(which, dtype, tol):
+    """the HIP CLIP text encoder against the (transformers-pinned) oracle: last hidden state, pooled
+    output, every hidden state, and the clip_skip branch's final_layer_norm."""
+    from gm_diffusion.components import CLIPTextModel
+    from oracle import clip_text as C
+
+    cfg = C.tiny_clip_config() if which == "tiny" else C.clip_l_config()
+    torch.manual_seed(11)
+    ref = C.CLIPTextModel(**cfg).eval()
+    with torch.no_grad():
+        for n, p_ in ref.named_parameters():
+            if "layer_norm" not in n:
+                p_.mul_(1.5)  # livelier logits than the default init
+    m = CLIPTextModel(**cfg)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV, dtype)
+    g = torch.Generator().manual_seed(12)
+    ids = torch.randint(3, cfg["vocab_size"] - 1, (3, 77), generator=g)
+    ids[0, 9] = ids[1, 76] = ids[2, 40] = cfg["vocab_size"] - 1
+    want = ref(ids, output_hidden_states=True)
+    got = m(ids.to(DEV), output_hidden_states=True)
+    assert got[0].shape == (3, 77, cfg["hidden_size"]) and got[0].dtype == dtype
+    assert rel_err(got[0].float(), want[0]) < tol
+    assert rel_err(got.pooler_output.float(), want[1]) < tol
+    assert len(got.hidden_states) == cfg["num_hidden_layers"] + 1
+    for a, b in zip(got[-1], want[2]):
+        assert rel_err(a.float(), b) < tol
+    skip = m.text_model.final_layer_norm(got[-1][-2])
+    assert rel_err(skip.float(), ref.text_model.final_layer_norm(want[2][-2]).detach()) < tol
+    with pytest.raises(IndexError):
+        m(torch.full((1, 77), cfg["vocab_size"], device=DEV))
+    with pytest.raises(Exception):
+        m(ids)  # host tensor: no CPU path

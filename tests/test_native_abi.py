@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu(native):
     assert lib.gmd_quantize_u8(None, None, -1, None) == 1
     assert lib.gmd_latent_step(None, None, None, None, None, None, 1, 16, 0, 1.0, None, 0.0, 7, 1.0, 1.0, 1.0, 1.0, 0.0, None, None, None, None) == 1
     assert b"mode" in lib.gmd_last_error()
-    assert lib.gmd_attention(None, None, None, None, native.GMD_F32, 1, 1, 40, 8, 8, 40, 40, 8, 40, 0, 0, 0, 0, 1.0, None) == 3  # UNSUPPORTED
+    assert lib.gmd_attention(None, None, None, None, native.GMD_F32, 1, 1, 40, 8, 8, 40, 40, 8, 40, 0, 0, 0, 0, 1.0, 0, None) == 3  # UNSUPPORTED
     assert lib.gmd_groupnorm_nsplit(4096) >= 1
 
 

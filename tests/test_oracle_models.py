@@ -113,3 +113,32 @@ def test_pipeline_goldens_reproduce(golden_dir):
     out = fixtures.fixture_dual_tiny_rescale()
     assert np.array_equal(out["latents"], g["latents"])
     assert np.allclose(out["sdr_out"], g["sdr_out"], atol=1e-5) and np.allclose(out["gm_out"], g["gm_out"], atol=1e-5)
+
+
+@pytest.mark.parametrize("which", ["tiny", "clip_l"])
+def test_clip_text_oracle_matches_transformers(which):
+    """the CLIP text encoder restatement is pinned against the installed ``transformers.CLIPTextModel``
+    (random weights from a config; the SD-1.5 text tower shape once)."""
+    tr = pytest.importorskip("transformers")
+    from oracle import clip_text as C
+
+    cfg = C.tiny_clip_config() if which == "tiny" else C.clip_l_config()
+    tcfg = tr.CLIPTextConfig(**{k: v for k, v in cfg.items()}, bos_token_id=0, pad_token_id=1)
+    torch.manual_seed(3)
+    ref = tr.CLIPTextModel(tcfg).eval()
+    mine = C.CLIPTextModel(**cfg).eval()
+    mine.load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(3, cfg["vocab_size"] - 1, (2, 77), generator=g)
+    ids[0, 20] = cfg["vocab_size"] - 1   # "EOS" = largest id (legacy eos rule), padded after it
+    ids[1, 76] = cfg["vocab_size"] - 1
+    with torch.no_grad():
+        r = ref(ids, output_hidden_states=True)
+    o = mine(ids, output_hidden_states=True)
+    assert torch.allclose(o[0], r.last_hidden_state, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(o[1], r.pooler_output, atol=2e-5, rtol=1e-5)
+    assert len(o[2]) == len(r.hidden_states) == cfg["num_hidden_layers"] + 1
+    for a, b in zip(o[2], r.hidden_states):
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-5)
+    if which == "clip_l":
+        assert sum(p.numel() for p in mine.parameters()) == 123_060_480  # public figure for the CLIP ViT-L/14 text tower

@@ -163,3 +163,60 @@ def test_dual_pipeline_dpm_solver_on_device_matches_oracle():
     rs, rg = OP.dual_loop(fixtures.build_unet("tiny", 4), fixtures.build_unet("tiny", 8), OS.DPMSolverMultistepScheduler(),
                           pe, ne, lat, 8, guidance_scale=7.5)
     assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
+
+
+class _ToyTokenizer:
+    """Stand-in for CLIPTokenizer (its BPE vocabulary is not available offline): the call protocol encode_prompt uses
+    (stable_diffusion_gm.py:398-407) over a deterministic word hash.  BOS = 0, EOS/pad = vocab-1 (largest id)."""
+
+    model_max_length = 77
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def __call__(self, text, padding=None, max_length=None, truncation=False, return_tensors="pt"):
+        from types import SimpleNamespace
+
+        texts = [text] if isinstance(text, str) else list(text)
+        rows = []
+        for t in texts:
+            ids = [0] + [3 + (sum(ord(ch) * (i + 1) for i, ch in enumerate(w)) % (self.vocab - 4)) for w in t.split()]
+            rows.append(ids[: (max_length or self.model_max_length) - 1] + [self.vocab - 1])
+        n = max_length if padding == "max_length" else max(len(r) for r in rows)
+        ids = torch.tensor([r + [self.vocab - 1] * (n - len(r)) for r in rows])
+        return SimpleNamespace(input_ids=ids, attention_mask=torch.ones_like(ids))
+
+    def batch_decode(self, ids):
+        return [" ".join(str(int(v)) for v in row) for row in ids]
+
+
+def test_dual_pipeline_from_prompts_with_hip_text_encoder():
+    """prompts in, latents out -- tokenizer protocol -> HIP CLIP text encoder -> both UNets; the oracle loop
+    is fed the oracle text encoder's hidden states for the same token ids."""
+    from gm_diffusion.components import CLIPTextModel
+    from oracle import clip_text as C, fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    cfg = C.tiny_clip_config()
+    torch.manual_seed(21)
+    oracle_te = C.CLIPTextModel(**cfg).eval()
+    te = CLIPTextModel(**cfg)
+    te.load_state_dict(oracle_te.state_dict())
+    pipe = _dual_pipe(torch.float32)
+    pipe.register_modules(text_encoder=te.to(DEV, torch.float32), tokenizer=_ToyTokenizer(cfg["vocab_size"]))
+    pipe.set_progress_bar_config(disable=True)
+    prompts, negs = ["a sunlit mountain lake at dawn", "neon city street"], ["blurry", ""]
+    lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(42))
+    sdr, gm = pipe(prompt=prompts, negative_prompt=negs, latents=lat.to(DEV), height=128, width=128, num_inference_steps=6,
+                   guidance_scale=7.5, output_type="latent")
+    tok = pipe.tokenizer
+    pe = oracle_te(tok(prompts, padding="max_length", max_length=77).input_ids)[0]
+    ne = oracle_te(tok(negs, padding="max_length", max_length=77).input_ids)[0]
+    rs, rg = OP.dual_loop(fixtures.build_unet("tiny", 4), fixtures.build_unet("tiny", 8), OS.PNDMScheduler(), pe, ne, lat, 6,
+                          guidance_scale=7.5)
+    assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
+    # clip_skip branch (stable_diffusion_gm.py:419-428): penultimate hidden state through final_layer_norm
+    a, _ = pipe.encode_prompt(prompts, DEV, 1, False, clip_skip=1)
+    want = oracle_te.text_model.final_layer_norm(oracle_te(tok(prompts, padding="max_length", max_length=77).input_ids, output_hidden_states=True)[2][-2])
+    assert rms(a, want.detach()) <= 1e-4
