@@ -95,7 +95,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path is hand-written HIP with no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # GMD_BENCH_FORCE_DIST=1 runs the RCCL path (process group, broadcasts, barrier, max-reduce) with a single rank too:
+    # the only way to exercise it on a one-GPU box
+    use_dist = world > 1 or (os.environ.get("GMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if a.gpus != world and rank == 0:
@@ -145,7 +148,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -176,9 +179,9 @@ def main():
         torch.cuda.synchronize()
         profiling.set_timer(None)
         pipe.overlap_streams = not a.no_overlap
-    if world > 1:
+    if use_dist:
         dist.barrier()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -218,7 +221,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
