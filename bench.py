@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--unet", default="sd15", choices=["sd15", "tiny"], help="tiny = structural smoke config (not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scheduler", default="pndm", choices=["pndm", "dpm++"],
+                    help="pndm = BASELINE.json's metric; dpm++ = the DPM-Solver++ swap of formal_improved.py:195 (side measurement)")
     ap.add_argument("--event-lead-ms", type=float, default=0.0, help="device-side delay queued before the instrumented step")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the GM UNet on the SDR stream instead of a second HIP stream")
@@ -105,7 +107,7 @@ def main():
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     from gm_diffusion import distributed as gdist, hdr, profiling
-    from gm_diffusion.components import AutoencoderKL, PNDMScheduler, UNet2DConditionModel
+    from gm_diffusion.components import AutoencoderKL, DPMSolverMultistepScheduler, PNDMScheduler, UNet2DConditionModel
     from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -118,6 +120,9 @@ def main():
     vae = AutoencoderKL(**vcfg).init_random(1334).to(dev, dtype)
     sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
                           skip_prk_steps=True, steps_offset=1, set_alpha_to_one=False)
+    if a.scheduler == "dpm++":
+        sched = DPMSolverMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                            timestep_spacing="leading")
     pipe = StableDiffusionDualUNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, gm_unet=gm_unet,
                                            scheduler=sched, safety_checker=None, feature_extractor=None,
                                            requires_safety_checker=False)
@@ -204,12 +209,13 @@ def main():
                                 "region (the timed region replays HIP graphs on two streams, which events cannot enter)",
                     "share_of_instrumented_kernel_time": round(dom["ms"] / sum(v["ms"] for v in full.values()), 3)}
         res = {
-            "metric": "HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet", "value": round(total * a.steps / elapsed, 4),
+            "metric": ("HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet" if a.scheduler == "pndm" and a.inference_steps == 50 and a.res == 512
+                       else f"HDR images/sec @ {a.res}x{a.res}, {a.inference_steps} {a.scheduler} steps, dual-UNet [not the BASELINE metric]"), "value": round(total * a.steps / elapsed, 4),
             "unit": "HDR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"SD-v1-5 dual-UNet (SDR 4ch + GM 8ch) {a.res}x{a.res}, {a.inference_steps} PNDM steps "
-                                   f"({a.inference_steps + 1} iterations), CFG 7.5, batch {B}/GPU, 2 VAE decodes + Eq.1 HDR tail"
+            "config": {"workload": f"SD-v1-5 dual-UNet (SDR 4ch + GM 8ch) {a.res}x{a.res}, {a.inference_steps} {a.scheduler.upper()} steps "
+                                   f"({a.inference_steps + (1 if a.scheduler == 'pndm' else 0)} iterations), CFG 7.5, batch {B}/GPU, 2 VAE decodes + Eq.1 HDR tail"
                                    + (" [TINY smoke config - not a valid bench]" if tiny else ""),
                        "global_batch": total, "per_gpu_batch": B, "resolution": a.res, "inference_steps": a.inference_steps,
                        "parallelism": f"prompt-batch sharding x{world}, RCCL broadcast of text hidden states + latents"},

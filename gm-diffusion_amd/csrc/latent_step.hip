@@ -46,6 +46,39 @@ __global__ __launch_bounds__(kThreads) void latent_step_kernel(
     }
 }
 
+// DPM-Solver++ (dpmsolver++ / midpoint / epsilon) multistep update fused with the CFG combine and both x0 forms, in the
+// operation order of the torch expressions of diffusers' DPMSolverMultistepScheduler (float32, no FMA contraction):
+//   m0     = (x - sigma_s0 * eps) / alpha_s0                                   convert_model_output
+//   order1 : x_prev = c_x * x - c_m * m0                                       dpm_solver_first_order_update
+//   order2 : x_prev = c_x * x - c_m * m0 - c_h * (inv_r0 * (m0 - m1))          multistep_dpm_solver_second_order_update
+// with c_x = sigma_t/sigma_s0, c_m = alpha_t*(exp(-h)-1), c_h = 0.5*c_m computed by the host in float32.
+__global__ __launch_bounds__(kThreads) void dpm_step_kernel(
+    const float* __restrict__ eps_in, const float* __restrict__ x, const float* __restrict__ m1, int B, int64_t chw, int do_cfg,
+    float gs, const float* __restrict__ ratio, float gr, int order, float sigma_s0, float alpha_s0, float c_x, float c_m, float c_h,
+    float inv_r0, float sqrt_a, float sqrt_1ma, float* __restrict__ m0_out, float* __restrict__ x_prev, float* __restrict__ x0) {
+    const int64_t n = (int64_t)B * chw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float eps;
+        if (do_cfg) {
+            const float u = eps_in[i], t = eps_in[n + i];
+            eps = u + gs * (t - u);  // dual.py:1065
+            if (ratio) {             // rescale_noise_cfg, dual.py:91-93
+                const float resc = eps * ratio[i / chw];
+                eps = gr * resc + (1.0f - gr) * eps;
+            }
+        } else {
+            eps = eps_in[i];
+        }
+        const float xt = x[i];
+        if (x0) x0[i] = (xt - sqrt_1ma * eps) / sqrt_a;  // dual.py:1075 (the pipeline's own x0, from alphas_cumprod[t])
+        const float m0 = (xt - sigma_s0 * eps) / alpha_s0;
+        m0_out[i] = m0;
+        float r = c_x * xt - c_m * m0;
+        if (order == 2) r = r - c_h * (inv_r0 * (m0 - m1[i]));
+        x_prev[i] = r;
+    }
+}
+
 // one block per sample: unbiased std over chw of text eps and of the guided eps
 __global__ __launch_bounds__(kThreads) void cfg_std_ratio_kernel(const float* __restrict__ eps_in, int B, int64_t chw,
                                                                  float gs, float* __restrict__ ratio) {
@@ -143,6 +176,23 @@ int gmd_latent_step(const float* eps_in, const float* x, const float* cur_sample
         eps_in, x, cur_sample, e1, e2, e3, B, chw, do_cfg, guidance_scale, do_cfg ? rescale_ratio : nullptr,
         guidance_rescale, mode, sample_coeff, alpha_delta, denom, sqrt_alpha, sqrt_one_minus_alpha, eps_out, x_prev, x0);
     GMD_CHECK_LAUNCH("gmd_latent_step");
+    return GMD_OK;
+}
+
+int gmd_dpm_step(const float* eps_in, const float* x, const float* m1, int B, int64_t chw, int do_cfg, float guidance_scale,
+                 const float* rescale_ratio, float guidance_rescale, int order, float sigma_s0, float alpha_s0, float c_x, float c_m,
+                 float c_h, float inv_r0, float sqrt_alpha, float sqrt_one_minus_alpha, float* m0_out, float* x_prev, float* x0,
+                 gmd_stream_t stream) {
+    GMD_REQUIRE(B >= 0 && chw > 0, "gmd_dpm_step: bad shape B=%d chw=%lld", B, (long long)chw);
+    if (B == 0) return GMD_OK;
+    GMD_REQUIRE(eps_in && x && m0_out && x_prev, "gmd_dpm_step: null pointer");
+    GMD_REQUIRE(order == 1 || order == 2, "gmd_dpm_step: order must be 1 or 2 (got %d)", order);
+    GMD_REQUIRE(order == 1 || m1, "gmd_dpm_step: the second-order update needs the previous x0 prediction");
+    GMD_REQUIRE(alpha_s0 != 0.0f && (x0 == nullptr || sqrt_alpha != 0.0f), "gmd_dpm_step: zero denominator");
+    dpm_step_kernel<<<grid_for((int64_t)B * chw), kThreads, 0, (hipStream_t)stream>>>(
+        eps_in, x, m1, B, chw, do_cfg, guidance_scale, do_cfg ? rescale_ratio : nullptr, guidance_rescale, order, sigma_s0, alpha_s0,
+        c_x, c_m, c_h, inv_r0, sqrt_alpha, sqrt_one_minus_alpha, m0_out, x_prev, x0);
+    GMD_CHECK_LAUNCH("gmd_dpm_step");
     return GMD_OK;
 }
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "gmd_quantize_u8": [P, P, L, P],
     "gmd_rgbe_encode": [P, P, L, P],
     "gmd_latent_step": [P, P, P, P, P, P, I, L, I, F, P, F, I, F, F, F, F, F, P, P, P, P],
+    "gmd_dpm_step": [P, P, P, I, L, I, F, P, F, I, F, F, F, F, F, F, F, F, P, P, P, P],
     "gmd_cfg_std_ratio": [P, I, L, F, P, P],
     "gmd_pack_unet_input": [P, I, P, I, I, L, I, P, I, I, P],
     "gmd_unpack_nchw": [P, I, L, I, I, L, P, P],

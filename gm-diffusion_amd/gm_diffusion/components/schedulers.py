@@ -300,8 +300,8 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
     Implements diffusers' ``dpmsolver++`` / ``midpoint`` / epsilon-prediction path with ``solver_order`` 1-2,
     ``lower_order_final`` and ``final_sigmas_type`` zero / sigma_min; Karras / exponential / beta sigma schedules,
     SDE variants and thresholding raise NotImplementedError.  A host-side state machine over the scheduler protocol:
-    ``step`` runs as torch expressions on whatever device holds the latents (the fused HIP latent-step kernel covers
-    PNDM)."""
+    ``step`` / ``fused_step`` run as ONE HIP kernel (gmd_dpm_step) for float32 device tensors, as the same torch
+    expressions on the host otherwise."""
 
     _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
                      solver_order=2, prediction_type="epsilon", thresholding=False, dynamic_thresholding_ratio=0.995,
@@ -381,7 +381,8 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
         else:
             self._step_index = idx[1] if len(idx) > 1 else idx[0]
 
-    def step(self, model_output, timestep, sample, generator=None, variance_noise=None, return_dict=True):
+    def _plan_step(self, timestep):
+        """Host side of one step: (order, float32 0-dim coefficient tensors) computed exactly as diffusers computes them."""
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         if self._step_index is None:
@@ -391,28 +392,63 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
         lower_order_final = (i == n - 1) and (c.euler_at_final or (c.lower_order_final and n < 15) or c.final_sigmas_type == "zero")
         lower_order_second = (i == n - 2) and c.lower_order_final and n < 15
         alpha_s0, sigma_s0 = self._sigma_to_alpha_sigma_t(self.sigmas[i])
-        x0_pred = (sample - sigma_s0 * model_output) / alpha_s0  # convert_model_output: dpmsolver++, epsilon
-        for k in range(c.solver_order - 1):
-            self.model_outputs[k] = self.model_outputs[k + 1]
-        self.model_outputs[-1] = x0_pred
-        sample = sample.to(torch.float32)
         alpha_t, sigma_t = self._sigma_to_alpha_sigma_t(self.sigmas[i + 1])
         lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
         lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
         h = lambda_t - lambda_s0
-        if c.solver_order == 1 or self.lower_order_nums < 1 or lower_order_final:
-            prev = (sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * x0_pred
-        elif c.solver_order == 2 or self.lower_order_nums < 2 or lower_order_second:
+        first = c.solver_order == 1 or self.lower_order_nums < 1 or lower_order_final
+        r0 = None
+        if not first:
+            assert c.solver_order == 2 or self.lower_order_nums < 2 or lower_order_second
             alpha_s1, sigma_s1 = self._sigma_to_alpha_sigma_t(self.sigmas[i - 1])
             lambda_s1 = torch.log(alpha_s1) - torch.log(sigma_s1)
-            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
-            h_0 = lambda_s0 - lambda_s1
-            r0 = h_0 / h
-            D0, D1 = m0, (1.0 / r0) * (m0 - m1)
-            prev = ((sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * D0
-                    - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1)
+            r0 = (lambda_s0 - lambda_s1) / h
+        return first, alpha_s0, sigma_s0, alpha_t, sigma_t, h, r0
+
+    def _advance(self, x0_pred):
+        c = self.config
+        for k in range(c.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = x0_pred
         if self.lower_order_nums < c.solver_order:
             self.lower_order_nums += 1
-        prev = prev.to(model_output.dtype)
         self._step_index += 1
+
+    def _device_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0):
+        """One HIP kernel pass (gmd_dpm_step): CFG combine (+rescale), pipeline x0, x0 prediction and the multistep update."""
+        first, alpha_s0, sigma_s0, alpha_t, sigma_t, h, r0 = self._plan_step(timestep)
+        c_x = sigma_t / sigma_s0
+        c_m = alpha_t * (torch.exp(-h) - 1.0)
+        c_h = 0.5 * c_m
+        inv_r0 = (1.0 / r0) if r0 is not None else torch.tensor(0.0)
+        a = self.alphas_cumprod[int(timestep)]  # the pipeline's own x0 (dual_unet.py:1072) uses the loop timestep
+        ratio = ops.cfg_std_ratio(eps_in, guidance_scale) if (do_cfg and guidance_rescale > 0.0) else None
+        m1 = None if first else self.model_outputs[-1]
+        m0, prev, x0 = ops.dpm_step(eps_in.contiguous(), sample.contiguous(), 1 if first else 2,
+                                    (sigma_s0.item(), alpha_s0.item(), c_x.item(), c_m.item(), c_h.item(), inv_r0.item(),
+                                     a.sqrt().item(), (1 - a).sqrt().item()),
+                                    do_cfg, guidance_scale, m1=m1, ratio=ratio, guidance_rescale=guidance_rescale, want_x0=want_x0)
+        self._advance(m0)
+        return prev, x0
+
+    def fused_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale=0.0, want_x0=False):
+        """Same contract as ``PNDMScheduler.fused_step`` (device tensors only).  Returns (prev_sample, x0 | None)."""
+        return self._device_step(eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0)
+
+    def step(self, model_output, timestep, sample, generator=None, variance_noise=None, return_dict=True):
+        if model_output.is_cuda and model_output.dtype == torch.float32 and sample.dtype == torch.float32:
+            prev, _ = self._device_step(model_output, timestep, sample, False, 1.0, 0.0, False)
+            return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)
+        first, alpha_s0, sigma_s0, alpha_t, sigma_t, h, r0 = self._plan_step(timestep)
+        x0_pred = (sample - sigma_s0 * model_output) / alpha_s0  # convert_model_output: dpmsolver++, epsilon
+        m1 = self.model_outputs[-1]
+        sample = sample.to(torch.float32)
+        if first:
+            prev = (sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * x0_pred
+        else:
+            D0, D1 = x0_pred, (1.0 / r0) * (x0_pred - m1)
+            prev = ((sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * D0
+                    - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1)
+        self._advance(x0_pred)
+        prev = prev.to(model_output.dtype)
         return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)

@@ -18,7 +18,7 @@ from . import profiling
 from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
+    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
     "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "groupnorm_split", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
@@ -366,6 +366,23 @@ def latent_step(eps_in, x, mode, coefs, do_cfg, guidance_scale, cur_sample=None,
                                 int(do_cfg), float(guidance_scale), _ptr(ratio), float(guidance_rescale), mode,
                                 sc, ad, dn, sa, s1, _ptr(eps_out), _ptr(x_prev), _ptr(x0), _stream()), "gmd_latent_step")
     return eps_out, x_prev, x0
+
+
+def dpm_step(eps_in, x, order, coefs, do_cfg, guidance_scale, m1=None, ratio=None, guidance_rescale=0.0, want_x0=False):
+    """Fused CFG + x0 + DPM-Solver++ (orders 1-2) update.  coefs = (sigma_s0, alpha_s0, c_x, c_m, c_h, inv_r0, sqrt_alpha,
+    sqrt_one_minus_alpha).  Returns (m0, x_prev, x0|None)."""
+    _dev(eps_in, x, m1, ratio)
+    for t in (eps_in, x, m1):
+        _f32(t, "latent tensors")
+    B = x.shape[0]
+    chw = x[0].numel()
+    m0 = torch.empty_like(x)
+    x_prev = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    c = [float(v) for v in coefs]
+    check(lib().gmd_dpm_step(_ptr(eps_in), _ptr(x), _ptr(m1), B, chw, int(do_cfg), float(guidance_scale), _ptr(ratio),
+                             float(guidance_rescale), int(order), *c, _ptr(m0), _ptr(x_prev), _ptr(x0), _stream()), "gmd_dpm_step")
+    return m0, x_prev, x0
 
 
 # ----------------------------------------------------------------------------------------------

@@ -308,7 +308,10 @@ class _GMPipelineBase(DiffusionPipeline):
     def _use_fused(self, latents, unet, scheduler):
         from ..components.unet_2d_condition import UNet2DConditionModel
 
-        return latents.is_cuda and isinstance(scheduler, PNDMScheduler) and isinstance(unet, UNet2DConditionModel)
+        from ..components.schedulers import DPMSolverMultistepScheduler
+
+        return (latents.is_cuda and isinstance(scheduler, (PNDMScheduler, DPMSolverMultistepScheduler))
+                and isinstance(unet, UNet2DConditionModel))
 
     def _default_hw(self, height, width):
         if not height or not width:

@@ -118,6 +118,18 @@ int gmd_latent_step(const float* eps_in, const float* x, const float* cur_sample
                     float sqrt_alpha, float sqrt_one_minus_alpha,
                     float* eps_out, float* x_prev, float* x0, gmd_stream_t stream);
 
+/* DPM-Solver++ multistep (dpmsolver++ / midpoint / epsilon, orders 1-2) -- the scheduler the reference swaps in for the
+ * dual-UNet runs (scripts/inference/experiments/formal_improved.py:195) -- fused with the same CFG combine / rescale and
+ * pipeline x0 as gmd_latent_step:
+ *   m0 = (x - sigma_s0*eps)/alpha_s0;  x_prev = c_x*x - c_m*m0 [ - c_h*(inv_r0*(m0 - m1)) when order == 2 ]
+ * c_x = sigma_t/sigma_s0, c_m = alpha_t*(exp(-h)-1), c_h = 0.5*c_m, inv_r0 = 1/r0: float32 scalars computed by the host
+ * exactly as diffusers computes its 0-dim tensors.  m0_out is the x0 prediction the host keeps for the next step. */
+int gmd_dpm_step(const float* eps_in, const float* x, const float* m1, int B, int64_t chw,
+                 int do_cfg, float guidance_scale, const float* rescale_ratio, float guidance_rescale,
+                 int order, float sigma_s0, float alpha_s0, float c_x, float c_m, float c_h, float inv_r0,
+                 float sqrt_alpha, float sqrt_one_minus_alpha,
+                 float* m0_out, float* x_prev, float* x0, gmd_stream_t stream);
+
 /* per-sample unbiased std of the text eps and of the guided eps -> ratio[b] = std_text/std_cfg
  * (rescale_noise_cfg, stable_diffusion_dual_unet.py:88-91) */
 int gmd_cfg_std_ratio(const float* eps_in, int B, int64_t chw, float guidance_scale,

@@ -537,3 +537,41 @@ def test_softmax_rows_causal_embedding_and_quick_gelu():
     assert rel_err(got, ref) < 1e-5
     gb = o.gemm_nt(x.bfloat16().to(DEV), w.bfloat16().to(DEV), bias=b.to(DEV), act=o.ACT_QUICK_GELU).float().cpu()
     assert rel_err(gb, ref) < 2e-2
+
+
+@pytest.mark.parametrize("do_cfg,gr", [(True, 0.0), (True, 0.7), (False, 0.0)])
+def test_dpm_step_kernel_bit_exact_vs_torch(do_cfg, gr):
+    """gmd_dpm_step against the torch expressions of the host path (= diffusers' operation order), over a whole 9-step
+    DPM-Solver++ trajectory: first-order start, second-order middle, lower-order final step with sigma_last = 0."""
+    from gm_diffusion.components import DPMSolverMultistepScheduler
+
+    mk = lambda: DPMSolverMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                                             timestep_spacing="leading")
+    host, dev = mk(), mk()
+    host.set_timesteps(9)
+    dev.set_timesteps(9)
+    g = torch.Generator().manual_seed(17)
+    B, gs = 2, 7.5
+    x = torch.randn(B, 4, 8, 8, generator=g)
+    xd = x.to(DEV)
+    for i, t in enumerate(host.timesteps):
+        raw = torch.randn((2 * B if do_cfg else B), 4, 8, 8, generator=g)
+        if do_cfg:
+            u, c = raw.chunk(2)
+            eps = u + gs * (c - u)
+            if gr > 0:
+                std_t = c.std(dim=list(range(1, c.ndim)), keepdim=True)
+                std_c = eps.std(dim=list(range(1, eps.ndim)), keepdim=True)
+                eps = gr * (eps * (std_t / std_c)) + (1 - gr) * eps
+        else:
+            eps = raw
+        a = host.alphas_cumprod[int(t)]
+        x0_ref = (x - (1 - a).sqrt() * eps) / a.sqrt()
+        x = host.step(eps, t, x, return_dict=False)[0]
+        xd, x0 = dev.fused_step(raw.to(DEV), int(t), xd, do_cfg, gs, gr, want_x0=True)
+        if gr == 0.0:
+            assert torch.equal(xd.cpu(), x), (i, float((xd.cpu() - x).abs().max()))
+            assert torch.equal(x0.cpu(), x0_ref)
+        else:  # the std ratio is reduced in a different order on the device
+            assert torch.allclose(xd.cpu(), x, atol=2e-5) and torch.allclose(x0.cpu(), x0_ref, atol=2e-5)
+    assert torch.isfinite(xd).all()

@@ -163,6 +163,13 @@ def test_dual_pipeline_dpm_solver_on_device_matches_oracle():
     rs, rg = OP.dual_loop(fixtures.build_unet("tiny", 4), fixtures.build_unet("tiny", 8), OS.DPMSolverMultistepScheduler(),
                           pe, ne, lat, 8, guidance_scale=7.5)
     assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
+    # the run above took the fused gmd_dpm_step path (+ HIP graphs, two streams); the generic scheduler-protocol path on the
+    # same models must agree to float32 rounding
+    assert pipe._use_fused(lat.to(DEV), pipe.unet, pipe.scheduler)
+    pipe._use_fused = lambda *args: False
+    s2, g2 = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+                  num_inference_steps=8, guidance_scale=7.5, output_type="latent")
+    assert rms(sdr, s2.cpu()) < 1e-5 and rms(gm, g2.cpu()) < 1e-5
 
 
 class _ToyTokenizer:
