@@ -87,6 +87,20 @@ __device__ __forceinline__ int64_t a_offset(const GemmParams& p, const RowCtx& r
     return (((int64_t)r.b * p.Hin + iy) * p.Win + ix) * p.Cin + c0;
 }
 
+// erf for the bf16 GEGLU epilogue: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (two orders below bf16 rounding) in ~14
+// instructions (one v_rcp, one v_exp) instead of libm's branchy erff -- the epilogue of the K=320 ff1 GEMM evaluates 32 of
+// them per thread for only 5 K steps of MFMA work.  The float32 parity path (gmd_geglu) keeps erff.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    y = y * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(1.0f - y, x);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == GMD_ACT_SILU) return silu_f(v);
     if (act == GMD_ACT_QUICK_GELU) return v / (1.0f + __expf(-1.702f * v));
@@ -209,7 +223,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
                     for (int e = 0; e < 4; ++e) {
                         const float h = acc[i][j][e] * p.alpha + bz[j][e];
                         const float g = acc[i][j + 1][e] * p.alpha + bz[j + 1][e];
-                        o4[e] = h * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+                        o4[e] = h * (0.5f * g * (1.0f + fast_erf(g * 0.70710678118654752440f)));
                     }
                     const int no = (nw + j * 16) / 2 + fq * 4;  // output column in [0, N/2)
                     bf16_t* o = (bf16_t*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + no;
