@@ -171,6 +171,7 @@ class _GraphedForward:
     x = None
     out = None
     graph = None
+    ws = None
 
     def replay(self):
         self.graph.replay()
@@ -589,9 +590,10 @@ class UNet2DConditionModel(_HipModule):
         cur.wait_stream(side)
         torch.cuda.synchronize(self._device)
         g.graph = torch.cuda.CUDAGraph()
+        g.ws = ops.new_workspace(self._device)  # this graph's own split-K scratch (see hip_ops.workspace_scope)
         self._capturing = True
         try:
-            with torch.cuda.graph(g.graph):
+            with ops.workspace_scope(g.ws), torch.cuda.graph(g.graph):
                 g.out = self.forward_packed(g.x, B, H, W, ehs)
         finally:
             self._capturing = False

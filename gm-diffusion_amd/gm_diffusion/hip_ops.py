@@ -56,9 +56,37 @@ _WS = {}
 WORKSPACE_BYTES = 96 << 20
 
 
+_WS_OVERRIDE = None
+
+
+class workspace_scope:
+    """Route every split-K launch issued inside the ``with`` block to ``ws`` (a float32 device tensor of
+    WORKSPACE_BYTES).  HIP-graph capture uses it: all captures run on torch's one capture stream, so the per-stream
+    table below would hand the SAME scratch to two graphs that are later replayed concurrently on different streams."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        global _WS_OVERRIDE
+        self.prev, _WS_OVERRIDE = _WS_OVERRIDE, self.ws
+        return self.ws
+
+    def __exit__(self, *exc):
+        global _WS_OVERRIDE
+        _WS_OVERRIDE = self.prev
+        return False
+
+
+def new_workspace(device):
+    return torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+
+
 def _workspace(device):
     """Persistent float32 scratch, one per (device, stream) so that concurrent streams never share it; it lets
     under-filled GEMM/conv launches split K."""
+    if _WS_OVERRIDE is not None:
+        return _WS_OVERRIDE
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
