@@ -170,6 +170,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timer = None
+    path_diff = None
     if not a.no_kernel_timing and rank == 0:
         timer = profiling.KernelTimer()
         profiling.set_timer(timer)  # an active timer makes the pipeline take the eager (non-graph) path
@@ -180,9 +181,12 @@ def main():
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record(); torch.cuda._sleep(20_000_000); c1.record(); torch.cuda.synchronize()
             torch.cuda._sleep(int(20_000_000 * a.event_lead_ms / max(c0.elapsed_time(c1), 1e-3)))
-        step()
+        out_eager = step()
         torch.cuda.synchronize()
         profiling.set_timer(None)
+        # the shipped path (graph replay, two streams) and this eager single-stream step run the same kernels on the same
+        # inputs: their HDR images must be bit-identical -- a full-size guard against cross-stream races
+        path_diff = float((out_eager["hdr"] - out["hdr"]).abs().max().item())
         pipe.overlap_streams = not a.no_overlap
     if use_dist:
         dist.barrier()
@@ -219,7 +223,7 @@ def main():
                                    + (" [TINY smoke config - not a valid bench]" if tiny else ""),
                        "global_batch": total, "per_gpu_batch": B, "resolution": a.res, "inference_steps": a.inference_steps,
                        "parallelism": f"prompt-batch sharding x{world}, RCCL broadcast of text hidden states + latents"},
-            "outputs_finite": finite, "setup_s": round(t_build, 1), "kernels": kernels, "roofline": roof,
+            "outputs_finite": finite, "graph_vs_eager_max_abs_diff": path_diff, "setup_s": round(t_build, 1), "kernels": kernels, "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
             try:
