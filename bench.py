@@ -207,6 +207,7 @@ def main():
             roof = {"kernel": "gmd_conv3x3 (gemm_ring_kernel<CONV=true>: implicit-GEMM conv3x3, 49.6% of UNet / 96.8% of VAE FLOPs)",
                     "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": BF16_DENSE_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(dom["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "traffic_note": "PMC needs its own rocprofv3 passes: profiles/r01_pmc_conv_hbm_traffic.txt (fabric reads 1.6x algorithmic)",
                     "launches": dom["launches"], "avg_launch_us": round(dom["avg_us"], 2),
                     "flops_per_launch_avg": round(dom["flops"] / dom["launches"]),
                     "measured": "HIP events around every conv3x3 launch of one extra eager, single-stream step after the timed "
