@@ -408,7 +408,8 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
         gmd_set_error("gmd_attention: only GMD_BF16 is implemented (the F32 parity path composes gmd_gemm_nt + gmd_softmax_rows)");
         return GMD_ERR_UNSUPPORTED;
     }
-    GMD_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "gmd_attention: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+    GMD_REQUIRE(B >= 0 && H > 0 && Nq >= 0 && Nk > 0, "gmd_attention: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+    if (B == 0 || Nq == 0) return GMD_OK;  // empty batch / no queries: nothing to write
     GMD_REQUIRE(B <= 65535 && H <= 65535, "gmd_attention: grid too large");
     GMD_REQUIRE(Q && K && Vt && O, "gmd_attention: null pointer");
     GMD_REQUIRE(gmd_aligned16(Q) && gmd_aligned16(K) && gmd_aligned16(Vt) && gmd_aligned16(O), "gmd_attention: pointers must be 16-byte aligned");

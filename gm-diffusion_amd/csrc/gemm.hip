@@ -941,7 +941,8 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_conv3x3: bad dtype %d", dtype);
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_conv3x3: out_dtype must be F32 or the input dtype");
-    GMD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "gmd_conv3x3: bad shape");
+    GMD_REQUIRE(B >= 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "gmd_conv3x3: bad shape");
+    if (B == 0) return GMD_OK;  // empty batch
     GMD_REQUIRE(stride == 1 || stride == 2, "gmd_conv3x3: stride must be 1 or 2");
     GMD_REQUIRE(!(upsample && stride != 1), "gmd_conv3x3: upsample requires stride 1");
     GMD_REQUIRE(pad_mode == 0 || (pad_mode == 1 && stride == 2 && !upsample), "gmd_conv3x3: pad_mode 1 requires stride 2");

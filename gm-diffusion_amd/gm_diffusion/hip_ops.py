@@ -384,7 +384,7 @@ def latent_step(eps_in, x, mode, coefs, do_cfg, guidance_scale, cur_sample=None,
     for t in (eps_in, x, cur_sample, *hist):
         _f32(t, "latent tensors")
     B = x.shape[0]
-    chw = x[0].numel()
+    chw = x.shape[1:].numel()
     eps_out = torch.empty_like(x)
     x_prev = torch.empty_like(x)
     x0 = torch.empty_like(x) if want_x0 else None
@@ -403,7 +403,7 @@ def dpm_step(eps_in, x, order, coefs, do_cfg, guidance_scale, m1=None, ratio=Non
     for t in (eps_in, x, m1):
         _f32(t, "latent tensors")
     B = x.shape[0]
-    chw = x[0].numel()
+    chw = x.shape[1:].numel()
     m0 = torch.empty_like(x)
     x_prev = torch.empty_like(x)
     x0 = torch.empty_like(x) if want_x0 else None

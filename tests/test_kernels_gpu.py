@@ -575,3 +575,20 @@ def test_dpm_step_kernel_bit_exact_vs_torch(do_cfg, gr):
         else:  # the std ratio is reduced in a different order on the device
             assert torch.allclose(xd.cpu(), x, atol=2e-5) and torch.allclose(x0.cpu(), x0_ref, atol=2e-5)
     assert torch.isfinite(xd).all()
+
+
+def test_empty_inputs_are_no_ops():
+    """Zero-sized batches go through every launcher as no-ops (empty result, no launch, no error)."""
+    o = ops()
+    bf = torch.bfloat16
+    e = lambda *s: torch.empty(*s, dtype=bf, device=DEV)
+    w = torch.zeros(64, 64, dtype=bf, device=DEV)
+    assert o.gemm_nt(e(0, 64), w).shape == (0, 64)
+    y, ho, wo = o.conv3x3(e(0, 64, 64), torch.zeros(64, 9 * 64, dtype=bf, device=DEV), 0, 8, 8)
+    assert y.shape == (0, 64, 64) and (ho, wo) == (8, 8)
+    assert o.attention(e(0, 16, 64), e(0, 16, 64), e(0, 64, 16), 2, 16, 1.0).shape == (0, 16, 64)
+    assert o.layernorm(e(0, 64), torch.ones(64, device=DEV), torch.zeros(64, device=DEV)).shape == (0, 64)
+    assert o.cast(e(0, 3), torch.float32).numel() == 0
+    z = torch.empty(0, 4, 8, 8, device=DEV)
+    eps, xp, x0 = o.latent_step(z, z, 0, (1.0, 0.5, 1.0, 1.0, 0.0), False, 1.0, want_x0=True)
+    assert xp.numel() == 0 and x0.numel() == 0
