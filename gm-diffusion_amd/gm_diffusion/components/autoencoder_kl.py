@@ -231,6 +231,8 @@ class AutoencoderKL(_HipModule):
         return self._resnet(m["r1"], x, B, H, W)
 
     # ---- public ------------------------------------------------------------------------------
+    max_tensor_bytes = (1 << 32) - 1  # addressable through one raw buffer descriptor
+
     def decode_nhwc(self, z):
         """z: float32 NCHW latents (already divided by scaling_factor).  Returns ([B, H*W, 4] float32
         channels-last image, channel 3 is padding), H, W."""
@@ -240,6 +242,16 @@ class AutoencoderKL(_HipModule):
         if z.dtype != torch.float32:
             z = ops.cast(z.contiguous(), torch.float32)
         B, _, H, W = z.shape
+        # The conv / GEMM kernels address a tensor with 32-bit byte offsets (raw buffer descriptors): keep the largest
+        # activation of the decoder -- the widest full-resolution tensor of the last up block -- under 4 GiB by decoding the
+        # batch in slices (16 images at 1024x1024 would need 8.6 GB for [B, 1024*1024, 256] in bf16).
+        up = 2 ** (len(c.block_out_channels) - 1)
+        widest = max(c.block_out_channels[0], c.block_out_channels[min(1, len(c.block_out_channels) - 1)])
+        per_image = H * up * W * up * widest * (2 if self._dtype == torch.bfloat16 else 4)
+        max_b = max(1, self.max_tensor_bytes // per_image)
+        if B > max_b:
+            parts = [self.decode_nhwc(z[i:i + max_b]) for i in range(0, B, max_b)]
+            return torch.cat([p[0] for p in parts]), parts[0][1], parts[0][2]
         x = ops.pack_unet_input(z.contiguous(), None, 1, self._lc_pad, self._dtype)
         x = ops.gemm_nt(x.view(B * H * W, self._lc_pad), w["pq"][0], bias=w["pq"][1]).view(B, H * W, self._lc_pad)
         x, _, _ = ops.conv3x3(x, w["d_in"][0], B, H, W, bias=w["d_in"][1])

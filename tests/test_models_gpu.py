@@ -152,3 +152,16 @@ def test_clip_text_encoder_matches_oracle(which, dtype, tol):
         m(torch.full((1, 77), cfg["vocab_size"], device=DEV))
     with pytest.raises(Exception):
         m(ids)  # host tensor: no CPU path
+
+
+def test_vae_decode_sliced_batch_equals_whole():
+    """Decoder batches whose widest activation would pass 4 GiB (32-bit buffer offsets) are decoded in slices: same result."""
+    from oracle import fixtures
+
+    m = _hip_vae(fixtures.build_vae("tiny"), torch.float32)
+    z = torch.randn(3, 4, 8, 8, generator=torch.Generator().manual_seed(2)).to(DEV)
+    whole, H, W = m.decode_nhwc(z)
+    m.max_tensor_bytes = 64 * 64 * 64 * 4 + 1  # room for one image's widest full-resolution activation only
+    parts, H2, W2 = m.decode_nhwc(z)
+    assert (H, W) == (H2, W2) == (64, 64) and parts.shape == whole.shape
+    assert rel_err(parts, whole) < 1e-5
