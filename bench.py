@@ -96,6 +96,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is hand-written HIP with no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # torchrun exports OMP_NUM_THREADS=1: the synthetic-weight set-up (1.8 G random floats per rank) would crawl on one thread
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
     dev = torch.device("cuda", local_rank)
     # GMD_BENCH_FORCE_DIST=1 runs the RCCL path (process group, broadcasts, barrier, max-reduce) with a single rank too:
     # the only way to exercise it on a one-GPU box
