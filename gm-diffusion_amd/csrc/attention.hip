@@ -25,7 +25,7 @@ struct AttnParams {
     const bf16_t* K;
     const bf16_t* Vt;
     bf16_t* O;
-    int Nq, Nk;
+    int Nq, Nk, H;
     int64_t ldq, ldk, ldvt, ldo, sQ, sK, sVt, sO;
     float scale_log2;  // softmax scale * log2(e)
 };
@@ -61,8 +61,21 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * 128 + wid * 32 + r;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so workgroup ids with equal
+    // id % 8 get a CONTIGUOUS run of (batch, head, query block) triples (bijective remap, as in the GEMM): the query blocks
+    // that stream the same K / V^T of one (batch, head) then share one L2 instead of fetching it through all eight.
+    int qb, head, b;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int qq = nwg >> 3, rr = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + j;
+        const int nqb = (p.Nq + 127) / 128;
+        qb = L % nqb;
+        const int t = L / nqb;
+        head = t % p.H;
+        b = t / p.H;
+    }
+    const int q = qb * 128 + wid * 32 + r;
     const bool qvalid = q < p.Nq;
     const bf16_t* Qb = p.Q + (int64_t)b * p.sQ + (int64_t)head * D;
     const bf16_t* Kb = p.K + (int64_t)b * p.sK + (int64_t)head * D;
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
 
     // CAUSAL (query q attends keys 0..q, Nq == Nk): key tiles entirely above the diagonal of this block's last query are
     // never visited (block-uniform bound)
-    const int ntiles = CAUSAL ? min((p.Nk + KV - 1) / KV, (min((int)blockIdx.x * 128 + 127, p.Nq - 1)) / KV + 1) : (p.Nk + KV - 1) / KV;
+    const int ntiles = CAUSAL ? min((p.Nk + KV - 1) / KV, (min(qb * 128 + 127, p.Nq - 1)) / KV + 1) : (p.Nk + KV - 1) / KV;
     // softmax scale inside the loop: the lagged variant folded it into Q
     const float c = kLagged ? 1.0f : p.scale_log2;
 
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
                     if (key >= p.Nk) st[t][i] = kNegBig;
                 }
         }
-        if (CAUSAL && k0 + KV - 1 > (int)blockIdx.x * 128 + wid * 32) {  // the tile reaches above this wave's first query
+        if (CAUSAL && k0 + KV - 1 > qb * 128 + wid * 32) {  // the tile reaches above this wave's first query
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -389,7 +402,7 @@ template <int D, bool CAUSAL = false>
 int launch_attn(const AttnParams& p, int B, int H, hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DT = (D + 31) / 32;
     const size_t smem = 2 * ((size_t)KV * (2 * DK + 1) * 16 + (size_t)DT * 32 * VROW);  // two pipeline stages
-    dim3 grid((p.Nq + 127) / 128, H, B);
+    dim3 grid(((p.Nq + 127) / 128) * H * B, 1, 1);  // 1-D: remapped per XCD in the kernel
     attn_fwd_kernel<D, CAUSAL><<<grid, 256, smem, s>>>(p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -410,7 +423,7 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
     }
     GMD_REQUIRE(B >= 0 && H > 0 && Nq >= 0 && Nk > 0, "gmd_attention: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     if (B == 0 || Nq == 0) return GMD_OK;  // empty batch / no queries: nothing to write
-    GMD_REQUIRE(B <= 65535 && H <= 65535, "gmd_attention: grid too large");
+    GMD_REQUIRE((int64_t)((Nq + 127) / 128) * H * B < (1ll << 31), "gmd_attention: grid too large");
     GMD_REQUIRE(Q && K && Vt && O, "gmd_attention: null pointer");
     GMD_REQUIRE(gmd_aligned16(Q) && gmd_aligned16(K) && gmd_aligned16(Vt) && gmd_aligned16(O), "gmd_attention: pointers must be 16-byte aligned");
     GMD_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "gmd_attention: leading dimensions must be multiples of 8 (ldo: 4)");
@@ -420,7 +433,7 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
     GMD_REQUIRE(ldq >= (int64_t)H * D && ldk >= (int64_t)H * D && ldo >= (int64_t)H * D, "gmd_attention: row stride smaller than H*D");
     AttnParams p;
     p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
-    p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+    p.Nq = Nq; p.Nk = Nk; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
     p.sQ = strideQ; p.sK = strideK; p.sVt = strideVt; p.sO = strideO;
     p.scale_log2 = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
