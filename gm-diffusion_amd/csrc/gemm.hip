@@ -447,12 +447,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
                    (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
     }
-    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(lds_addr), "s"(desc)
-                     : "memory");
+    // see gemm_ring_kernel::dma16 (M0 clobbered, K offset as soffset)
+    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                     :
+                     : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                     : "memory", "m0");
+#pragma clang diagnostic pop
     };
     auto dma_tile = [&](int kt, int buf) {
         const unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
@@ -468,9 +471,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         }
         const unsigned stage = lds_base + (unsigned)buf * kStage + (unsigned)wuni * (8 * 128);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (32 * 128), aoff[i] + abytes);
+        for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (32 * 128), aoff[i], abytes);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) dma16(dW, stage + BM * 128 + i * (32 * 128), woff[i] + kbytes);
+        for (int i = 0; i < NW; ++i) dma16(dW, stage + BM * 128 + i * (32 * 128), woff[i], kbytes);
         if (CONV) {
             c0 += BK;
             if (c0 >= p.Cin) { c0 = 0; ++tap; newtap = true; }
@@ -632,12 +635,18 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
         dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
                    (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
     }
-    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(lds_addr), "s"(desc)
-                     : "memory");
+    // (M0 is a reserved register: nothing else in this kernel reads it -- gfx950 LDS instructions do not -- so it is listed as
+    // clobbered and the compiler's "reserved register" diagnostic is silenced for this statement only)
+    // one LDS-DMA piece: M0 = wave-uniform LDS destination, per-lane row offset in a VGPR, the K offset of the tile as the
+    // scalar soffset (no VALU add per piece); M0 is declared clobbered instead of saved / restored around every piece
+    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                     :
+                     : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                     : "memory", "m0");
+#pragma clang diagnostic pop
     };
     auto dma_tile = [&](int kt, int stage_idx) {
         const unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
@@ -653,10 +662,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
         }
         const unsigned stage = lds_base + (unsigned)stage_idx * kStage + (unsigned)wuni * (8 * 128);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (RPP * 128), aoff[i] + abytes);
+        for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (RPP * 128), aoff[i], abytes);
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            if (i + 1 < NW || w_last) dma16(dW, stage + BM * 128 + i * (RPP * 128), woff[i] + kbytes);
+            if (i + 1 < NW || w_last) dma16(dW, stage + BM * 128 + i * (RPP * 128), woff[i], kbytes);
         }
         if (CONV) {
             c0 += BK;
