@@ -227,3 +227,43 @@ def test_dual_pipeline_from_prompts_with_hip_text_encoder():
     a, _ = pipe.encode_prompt(prompts, DEV, 1, False, clip_skip=1)
     want = oracle_te.text_model.final_layer_norm(oracle_te(tok(prompts, padding="max_length", max_length=77).input_ids, output_hidden_states=True)[2][-2])
     assert rms(a, want.detach()) <= 1e-4
+
+
+@pytest.mark.parametrize("output_type", ["np", "pt"])
+def test_pipelines_decode_outputs_on_device_path(golden_dir, output_type):
+    """Non-latent output types (stable_diffusion_gm.py:1093-1107, dual_unet.py:1115-1131): the product decodes with the HIP
+    VAE + image processor; compared with the oracle VAE decode of the golden latents (denorm + clamp)."""
+    from gm_diffusion.components import AutoencoderKL, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionDualUNetImprovedPipeline, StableDiffusionGMPipeline
+    from oracle import fixtures
+
+    ov = fixtures.build_vae("tiny")
+
+    def ref_img(lat):
+        dec = ov.decode(torch.as_tensor(lat) / ov.config.scaling_factor, return_dict=False)[0]
+        return (dec / 2 + 0.5).clamp(0, 1).detach()
+
+    def as_nchw(x):
+        return x.cpu() if output_type == "pt" else torch.from_numpy(np.asarray(x)).permute(0, 3, 1, 2)
+
+    g = np.load(os.path.join(golden_dir, "pipeline_oracle_dual_tiny.npz"))
+    pipe = _dual_pipe(torch.float32)
+    pipe.__class__ = StableDiffusionDualUNetImprovedPipeline  # same implementation under the second exported name
+    pipe.set_progress_bar_config(disable=True)
+    sdr_img, gm_img = pipe(prompt_embeds=torch.from_numpy(g["prompt_embeds"]).to(DEV),
+                           negative_prompt_embeds=torch.from_numpy(g["negative_prompt_embeds"]).to(DEV),
+                           latents=torch.from_numpy(g["latents"]).to(DEV), height=128, width=128, num_inference_steps=10,
+                           guidance_scale=7.5, output_type=output_type)
+    assert rms(as_nchw(sdr_img), ref_img(g["sdr_out"])) < 2e-3 and rms(as_nchw(gm_img), ref_img(g["gm_out"])) < 2e-3
+
+    g = np.load(os.path.join(golden_dir, "pipeline_oracle_gm_tiny.npz"))
+    gp = StableDiffusionGMPipeline(
+        vae=_hip(AutoencoderKL, ov, torch.float32), text_encoder=None, tokenizer=None,
+        unet=_hip(UNet2DConditionModel, fixtures.build_unet("tiny", 8), torch.float32), scheduler=_pndm(),
+        safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    gp.set_progress_bar_config(disable=True)
+    out = gp(torch.from_numpy(g["sdr_latent"]).to(DEV), prompt_embeds=torch.from_numpy(g["prompt_embeds"]).to(DEV),
+             negative_prompt_embeds=torch.from_numpy(g["negative_prompt_embeds"]).to(DEV),
+             latents=torch.from_numpy(g["latents"]).to(DEV), num_inference_steps=10, guidance_scale=7.5, output_type=output_type)
+    assert out.nsfw_content_detected is None
+    assert rms(as_nchw(out.images), ref_img(g["out"])) < 2e-3
