@@ -455,18 +455,21 @@ class UNet2DConditionModel(_HipModule):
         The buffers are persistent per (layer, shape) and rewritten in place for new embeddings, so a captured HIP
         graph of the forward keeps reading valid addresses."""
         key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
-        ent = self._kv_cache.get(t["key"])
+        B, L, E = ehs.shape
+        # one persistent buffer pair per (layer, batch, tokens): a graph captured for one batch size must keep finding ITS
+        # buffers after the model has served another batch size in between
+        slot = (t["key"], B, L, self._dtype)
+        ent = self._kv_cache.get(slot)
         if ent is not None and ent["key"] == key:
             return ent["kc"], ent["vt"]
         if self._capturing:
             raise HipExtensionError("cross-attention K/V must be prepared (update_context) before graph capture")
-        B, L, E = ehs.shape
         C = t["k2"].shape[0]
         lpad = _pad_to(L, 8 if self._dtype == torch.bfloat16 else 4)
-        if ent is None or tuple(ent["kc"].shape) != (B, L, C) or ent["kc"].dtype != self._dtype:
+        if ent is None:
             ent = dict(kc=torch.empty((B, L, C), dtype=self._dtype, device=ehs.device),
                        vt=torch.zeros((B, C, lpad), dtype=self._dtype, device=ehs.device))
-            self._kv_cache[t["key"]] = ent
+            self._kv_cache[slot] = ent
         ops.gemm_nt(ehs.view(B * L, E), t["k2"], out=ent["kc"].view(B * L, C))
         ops.gemm_nt(t["v2"], ehs, out=ent["vt"], ldc=lpad)
         ent["key"] = key

@@ -267,3 +267,43 @@ def test_pipelines_decode_outputs_on_device_path(golden_dir, output_type):
              latents=torch.from_numpy(g["latents"]).to(DEV), num_inference_steps=10, guidance_scale=7.5, output_type=output_type)
     assert out.nsfw_content_detected is None
     assert rms(as_nchw(out.images), ref_img(g["out"])) < 2e-3
+
+
+def test_dual_pipeline_option_matrix_on_device():
+    """Call options of the reference signature on the fused device path, each against the oracle loop: no CFG
+    (guidance_scale <= 1: single-batch SDR UNet), num_images_per_prompt > 1 (embeddings repeated per prompt,
+    stable_diffusion_dual_unet.py:455-457), latents drawn from a CPU generator (randn_tensor), the legacy ``callback`` (the reference's dual loop has its
+    ``callback_on_step_end`` block commented out, stable_diffusion_dual_unet.py:1095-1104: accepted, never called)."""
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    pipe = _dual_pipe(torch.float32)
+    pipe.set_progress_bar_config(disable=True)
+    ou, og = fixtures.build_unet("tiny", 4), fixtures.build_unet("tiny", 8)
+    pe, ne, lat = fixtures.make_inputs(2, 16, 16, cross_dim=64)
+
+    # 1. no classifier-free guidance
+    sdr, gm = pipe(prompt_embeds=pe.to(DEV), latents=lat.to(DEV), height=128, width=128, num_inference_steps=5, guidance_scale=1.0,
+                   output_type="latent")
+    rs, rg = OP.dual_loop(ou, og, OS.PNDMScheduler(), pe, ne, lat, 5, guidance_scale=1.0)
+    assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
+
+    # 2. two images per prompt: rows [p0, p0, p1, p1]
+    lat4 = torch.randn(4, 4, 16, 16, generator=torch.Generator().manual_seed(9))
+    seen = []
+    sdr, gm = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat4.to(DEV), height=128, width=128,
+                   num_inference_steps=5, guidance_scale=6.0, num_images_per_prompt=2, output_type="latent",
+                   callback=lambda i, t, x: seen.append((i, int(t))), callback_steps=1,
+                   callback_on_step_end=lambda *a: (_ for _ in ()).throw(AssertionError("the reference never calls it")))
+    rs, rg = OP.dual_loop(ou, og, OS.PNDMScheduler(), pe.repeat_interleave(2, 0), ne.repeat_interleave(2, 0), lat4, 5, guidance_scale=6.0)
+    assert sdr.shape == (4, 4, 16, 16) and rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
+    # 5 PNDM steps = 6 iterations, one of them a scheduler warm-up step (num_warmup_steps = 6 - 5): no callback there
+    assert [i for i, _ in seen] == [1, 2, 3, 4, 5] and seen[0][1] > seen[-1][1]
+
+    # 3. latents from a generator: randn_tensor draws on the generator's device (CPU) and moves the result
+    a = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), height=128, width=128, num_inference_steps=3,
+             generator=torch.Generator().manual_seed(5), output_type="latent")
+    want = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    rs, rg = OP.dual_loop(ou, og, OS.PNDMScheduler(), pe, ne, want, 3, guidance_scale=7.5)
+    assert rms(a[0], rs) <= RMS_TOL and rms(a[1], rg) <= RMS_TOL
