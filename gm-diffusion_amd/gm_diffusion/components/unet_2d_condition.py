@@ -180,6 +180,7 @@ class _GraphedForward:
 
 class UNet2DConditionModel(_HipModule):
     config_name = "config.json"
+    max_cached_graphs = 8  # captured forwards kept per model (one per batch / latent size / token count)
     _defaults = SD15_UNET_DEFAULTS
 
     def __init__(self, **config):
@@ -600,6 +601,8 @@ class UNet2DConditionModel(_HipModule):
                 g.out = self.forward_packed(g.x, B, H, W, ehs)
         finally:
             self._capturing = False
+        while len(self._graphs) >= self.max_cached_graphs:  # oldest first: a graph pins its activations pool and 96 MB of scratch
+            self._graphs.pop(next(iter(self._graphs)))
         self._graphs[key] = g
         return g
 

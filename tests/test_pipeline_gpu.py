@@ -307,3 +307,51 @@ def test_dual_pipeline_option_matrix_on_device():
     want = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
     rs, rg = OP.dual_loop(ou, og, OS.PNDMScheduler(), pe, ne, want, 3, guidance_scale=7.5)
     assert rms(a[0], rs) <= RMS_TOL and rms(a[1], rg) <= RMS_TOL
+
+
+def test_graph_cache_survives_shape_switching():
+    """A long-lived pipeline serving changing batch sizes and resolutions (cached graphs, persistent K/V buffers, per-graph
+    workspaces) must return exactly what a fresh pipeline returns for each request."""
+    g = torch.Generator().manual_seed(31)
+    reqs = []
+    for b, res in [(1, 128), (2, 128), (1, 64), (2, 128), (3, 64), (1, 128), (2, 64)]:
+        h = res // 8
+        reqs.append(dict(prompt_embeds=torch.randn(b, 77, 64, generator=g).to(DEV), negative_prompt_embeds=torch.randn(b, 77, 64, generator=g).to(DEV),
+                         latents=torch.randn(b, 4, h, h, generator=g).to(DEV), height=res, width=res, num_inference_steps=4,
+                         guidance_scale=5.0, output_type="latent"))
+    served = _dual_pipe(torch.bfloat16)
+    served.set_progress_bar_config(disable=True)
+    got = [served(**r) for r in reqs]
+    torch.cuda.synchronize()
+    for r, out in zip(reqs, got):
+        fresh = _dual_pipe(torch.bfloat16)
+        fresh.set_progress_bar_config(disable=True)
+        want = fresh(**r)
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]), (r["latents"].shape,)
+
+
+def test_gm_pipeline_option_matrix_on_device(golden_dir):
+    """StableDiffusionGMPipeline options on the fused path vs the oracle loop: no CFG, two images per prompt with the SDR
+    latent repeated as the reference does (stable_diffusion_gm.py:1012-1024), callback_on_step_end edits."""
+    from gm_diffusion.components import AutoencoderKL, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionGMPipeline
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    ou = fixtures.build_unet("tiny", 8)
+    pipe = StableDiffusionGMPipeline(
+        vae=_hip(AutoencoderKL, fixtures.build_vae("tiny"), torch.float32), text_encoder=None, tokenizer=None,
+        unet=_hip(UNet2DConditionModel, ou, torch.float32), scheduler=_pndm(), safety_checker=None, feature_extractor=None,
+        requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    pe, ne, lat = fixtures.make_inputs(2, 16, 16, cross_dim=64)
+    sdr_lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(77))
+    out = pipe(sdr_lat.to(DEV), prompt_embeds=pe.to(DEV), latents=lat.to(DEV), num_inference_steps=5, guidance_scale=1.0,
+               output_type="latent").images
+    ref = OP.gm_loop(ou, OS.PNDMScheduler(), sdr_lat, pe, ne, lat, 5, guidance_scale=1.0)
+    assert rms(out, ref) <= RMS_TOL
+    out = pipe(sdr_lat.to(DEV), prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV),
+               num_inference_steps=5, guidance_scale=4.0, output_type="latent").images
+    ref = OP.gm_loop(ou, OS.PNDMScheduler(), sdr_lat, pe, ne, lat, 5, guidance_scale=4.0)
+    assert rms(out, ref) <= RMS_TOL
