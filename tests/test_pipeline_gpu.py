@@ -355,3 +355,25 @@ def test_gm_pipeline_option_matrix_on_device(golden_dir):
                num_inference_steps=5, guidance_scale=4.0, output_type="latent").images
     ref = OP.gm_loop(ou, OS.PNDMScheduler(), sdr_lat, pe, ne, lat, 5, guidance_scale=4.0)
     assert rms(out, ref) <= RMS_TOL
+
+
+@pytest.mark.parametrize("L", [20, 154])
+def test_dual_pipeline_other_token_counts(L):
+    """Text conditioning shorter / longer than CLIP's 77 tokens (e.g. concatenated prompt chunks): 1 and 3 key tiles."""
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    pipe = _dual_pipe(torch.float32)
+    pipe.set_progress_bar_config(disable=True)
+    pe, ne, lat = fixtures.make_inputs(2, 16, 16, cross_dim=64, seq=L)
+    sdr, gm = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+                   num_inference_steps=4, guidance_scale=7.5, output_type="latent")
+    rs, rg = OP.dual_loop(fixtures.build_unet("tiny", 4), fixtures.build_unet("tiny", 8), OS.PNDMScheduler(), pe, ne, lat, 4,
+                          guidance_scale=7.5)
+    assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
+    pb = _dual_pipe(torch.bfloat16)
+    pb.set_progress_bar_config(disable=True)
+    sb, gb = pb(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+                num_inference_steps=4, guidance_scale=7.5, output_type="latent")
+    assert rms(sb, rs) < 0.2 and rms(gb, rg) < 0.2 and torch.isfinite(sb).all()
