@@ -369,3 +369,53 @@ def test_dual_pipeline_with_dpm_solver(unets):
              guidance_scale=9.0, eta=0.7, output_type="latent")  # eta is dropped: step() takes none (gm.py:610-625)
     ra, rb = OP.dual_loop(unets[0], unets[1], OS.DPMSolverMultistepScheduler(), pe, ne, lat, 5, guidance_scale=9.0)
     assert torch.allclose(a, ra, atol=1e-5) and torch.allclose(b, rb, atol=1e-5)
+
+
+def test_pipeline_from_pretrained_directory(tmp_path):
+    """Whole-pipeline load as scripts/inference/generate_hdr.py:152-176 does it: an SD-1.5-layout directory
+    (model_index.json + unet/ vae/ text_encoder/ scheduler/), components passed as keyword arguments replace the ones on disk,
+    ``["transformers", "CLIPTextModel"]`` resolves to the HIP text encoder, gm_unet must be given explicitly."""
+    import json
+
+    from safetensors.torch import save_file
+
+    from gm_diffusion.components import AutoencoderKL, CLIPTextModel, UNet2DConditionModel
+    from oracle import clip_text as C
+
+    root = tmp_path / "ckpt"
+    ou, ov = fixtures.build_unet("tiny", 4), fixtures.build_vae("tiny")
+    hu = UNet2DConditionModel(**vars(ou.config))
+    hu.load_state_dict(ou.state_dict())
+    hu.save_pretrained(str(root / "unet"))
+    os.makedirs(root / "vae")
+    json.dump({"_class_name": "AutoencoderKL", **{k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(ov.config).items()}},
+              open(root / "vae" / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in ov.state_dict().items()}, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    tcfg = C.tiny_clip_config()
+    ote = C.CLIPTextModel(**tcfg)
+    os.makedirs(root / "text_encoder")
+    json.dump({"architectures": ["CLIPTextModel"], **tcfg}, open(root / "text_encoder" / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in ote.state_dict().items()}, str(root / "text_encoder" / "model.safetensors"))
+    os.makedirs(root / "scheduler")
+    json.dump({"_class_name": "PNDMScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "skip_prk_steps": True, "steps_offset": 1, "num_train_timesteps": 1000, "set_alpha_to_one": False},
+              open(root / "scheduler" / "scheduler_config.json", "w"))
+    json.dump({"_class_name": "StableDiffusionPipeline", "unet": ["diffusers", "UNet2DConditionModel"], "vae": ["diffusers", "AutoencoderKL"],
+               "text_encoder": ["transformers", "CLIPTextModel"], "tokenizer": ["transformers", "CLIPTokenizer"],
+               "scheduler": ["diffusers", "PNDMScheduler"], "safety_checker": ["stable_diffusion", "StableDiffusionSafetyChecker"],
+               "feature_extractor": ["transformers", "CLIPImageProcessor"], "requires_safety_checker": True},
+              open(root / "model_index.json", "w"))
+    gm = UNet2DConditionModel(**vars(ou.config)).load_state_dict(ou.state_dict()).replace_conv_in(8)
+    with pytest.raises(ValueError, match="gm_unet"):
+        StableDiffusionDualUNetPipeline.from_pretrained(str(root), tokenizer=None, safety_checker=None)
+    pipe = StableDiffusionDualUNetPipeline.from_pretrained(str(root), gm_unet=gm, tokenizer=None, safety_checker=None,
+                                                           requires_safety_checker=False)
+    assert isinstance(pipe.unet, UNet2DConditionModel) and isinstance(pipe.vae, AutoencoderKL) and isinstance(pipe.text_encoder, CLIPTextModel)
+    assert isinstance(pipe.scheduler, PNDMScheduler) and pipe.gm_unet is gm and pipe.safety_checker is None and pipe.tokenizer is None
+    assert pipe.gm_unet.config.in_channels == 8 and pipe.unet.config.in_channels == 4
+    assert all(torch.equal(pipe.text_encoder.state_dict()["text_model." + k if not k.startswith("text_model.") else k], v)
+               for k, v in ote.state_dict().items())
+    assert pipe.vae_scale_factor == 8 and pipe.text_encoder.config.hidden_size == tcfg["hidden_size"]
+    # single-UNet pipeline from the same directory with the 8-channel UNet passed in (generate_hdr.py:169-176)
+    gp = StableDiffusionGMPipeline.from_pretrained(str(root), unet=gm, tokenizer=None, safety_checker=None, requires_safety_checker=False)
+    assert gp.unet is gm and isinstance(gp.vae, AutoencoderKL)
