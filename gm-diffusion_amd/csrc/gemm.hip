@@ -288,6 +288,65 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
     }
 }
 
+// Row-contiguous epilogue through LDS (full bf16 tiles without split-K / GEGLU).  The register epilogue above writes, per
+// store instruction, 16 rows x 32 bytes; the store path is transaction-bound (a float32 output, twice the bytes in the same
+// number of instructions, takes exactly the same time), which makes the small-K linear layers epilogue-bound.  Here each
+// wave parks its raw accumulators in a private LDS strip (two halves of 32 rows; the K-loop stages are dead by then),
+// reads them back row-major and issues 16-byte stores that cover whole 128/160-byte row segments; bias, row bias,
+// residual (16-byte loads, same shape) and activation are applied on the way out in float32, bit-identical to the
+// register epilogue.  Caller guarantees: block tile fully inside M x N, ldc / ldr / batch strides multiples of 8, and a
+// __syncthreads() between the last LDS read of the K loop and this call.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
+                                              int z) {
+    static_assert(TM == 4, "two halves of two 16-row tiles");
+    constexpr int NCOL = TN * 16, ROWF = NCOL + 4, CH = NCOL / 8;
+    constexpr int ITER = (32 * CH + 63) / 64;
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + j * 16 + fq * 4) =
+                    make_float4(acc[2 * h + i2][j][0], acc[2 * h + i2][j][1], acc[2 * h + i2][j][2], acc[2 * h + i2][j][3]);
+        __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS: only the compiler must not reorder across this point
+#pragma unroll
+        for (int t = 0; t < ITER; ++t) {
+            const int idx = lane + 64 * t;
+            const int r = idx / CH, c = idx - r * CH;
+            if (32 * CH % 64 != 0 && r >= 32) continue;
+            const int m = mw + h * 32 + r, n = nw + c * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 8);
+            const float4 a1 = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 8 + 4);
+            float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.residual) {
+                const uint4 w = *reinterpret_cast<const uint4*>((const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
+                const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { add[2 * e] = __uint_as_float(ww[e] << 16); add[2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
+            }
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb + n;
+                const float4 t0 = *reinterpret_cast<const float4*>(rb), t1 = *reinterpret_cast<const float4*>(rb + 4);
+                add[0] += t0.x; add[1] += t0.y; add[2] += t0.z; add[3] += t0.w; add[4] += t1.x; add[5] += t1.y; add[6] += t1.z; add[7] += t1.w;
+            }
+            float bz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const float4 t0 = *reinterpret_cast<const float4*>(p.bias + n), t1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+                bz[0] = t0.x; bz[1] = t0.y; bz[2] = t0.z; bz[3] = t0.w; bz[4] = t1.x; bz[5] = t1.y; bz[6] = t1.z; bz[7] = t1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs
+            bf16_t* o = (bf16_t*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+            *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int V> struct IntC { static constexpr int value = V; };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -717,7 +776,18 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
             st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
         }
     }
-    epilogue_regs<TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+    // block-uniform choice: full bf16 tile, plain epilogue -> row-contiguous stores through LDS
+    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
+                         (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
+                         (p.rowbias == nullptr || (p.ldrb & 3) == 0);
+    if (rows_ok) {
+        __syncthreads();  // every wave is done with the K-loop stages: the strips below overwrite them
+        constexpr int kStrip = 32 * (TN * 16 + 4);  // floats per wave
+        static_assert((size_t)NWAVES * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
+        epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+    } else {
+        epilogue_regs<TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
