@@ -347,6 +347,51 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
     }
 }
 
+// GEGLU variant of epilogue_rows: h * gelu(g) is formed in registers exactly as in epilogue_regs (value / gate tiles of a
+// pair sit in the same lane), staged, and written as [M, N/2] rows with 16-byte stores.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_geglu(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw,
+                                                    int lane, int z) {
+    static_assert(TM == 4 && TN % 2 == 0, "two halves of two 16-row tiles; value/gate tile pairs");
+    constexpr int NCOL = TN * 8, ROWF = NCOL + 4, CH = NCOL / 8;  // output columns of this wave
+    constexpr int ITER = (32 * CH + 63) / 64;
+    const int frow = lane & 15, fq = lane >> 4;
+    float bz[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float4 t = p.bias ? *reinterpret_cast<const float4*>(p.bias + nw + j * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bz[j][0] = t.x; bz[j][1] = t.y; bz[j][2] = t.z; bz[j][3] = t.w;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                float o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hv = acc[2 * h + i2][j][e] * p.alpha + bz[j][e];
+                    const float g = acc[2 * h + i2][j + 1][e] * p.alpha + bz[j + 1][e];
+                    o4[e] = hv * (0.5f * g * (1.0f + fast_erf(g * 0.70710678118654752440f)));
+                }
+                *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + (j / 2) * 16 + fq * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < ITER; ++t) {
+            const int idx = lane + 64 * t;
+            const int r = idx / CH, c = idx - r * CH;
+            if (32 * CH % 64 != 0 && r >= 32) continue;
+            const float4 a0 = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 8);
+            const float4 a1 = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 8 + 4);
+            bf16_t* o = (bf16_t*)p.C + (int64_t)z * p.sC + (int64_t)(mw + h * 32 + r) * p.ldc + nw / 2 + c * 8;
+            *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(a0.x, a0.y), pack_bf16x2(a0.z, a0.w), pack_bf16x2(a1.x, a1.y), pack_bf16x2(a1.z, a1.w));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int V> struct IntC { static constexpr int value = V; };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -780,6 +825,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
     const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
                          (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
                          (p.rowbias == nullptr || (p.ldrb & 3) == 0);
+    if constexpr (TN % 2 == 0) {
+        if (p.act == GMD_ACT_GEGLU && !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 && (p.sC & 7) == 0) {
+            __syncthreads();
+            constexpr int kStripG = 32 * (TN * 8 + 4);
+            epilogue_rows_geglu<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+            return;
+        }
+    }
     if (rows_ok) {
         __syncthreads();  // every wave is done with the K-loop stages: the strips below overwrite them
         constexpr int kStrip = 32 * (TN * 16 + 4);  // floats per wave
