@@ -347,6 +347,37 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
     }
 }
 
+// Split-K variant of epilogue_rows: the raw float32 partial sums of a full tile go to this slice's slab as whole row
+// segments (16-byte stores, 64 * TN bytes contiguous per row) instead of 64-byte pieces of 16 rows per instruction.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_slab(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
+                                                   int ks) {
+    static_assert(TM == 4, "two halves of two 16-row tiles");
+    constexpr int NCOL = TN * 16, ROWF = NCOL + 4, CH = NCOL / 4;
+    constexpr int ITER = (32 * CH + 63) / 64;
+    const int frow = lane & 15, fq = lane >> 4;
+    float* slab = p.ws + (int64_t)ks * p.M * p.N;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + j * 16 + fq * 4) =
+                    make_float4(acc[2 * h + i2][j][0], acc[2 * h + i2][j][1], acc[2 * h + i2][j][2], acc[2 * h + i2][j][3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < ITER; ++t) {
+            const int idx = lane + 64 * t;
+            const int r = idx / CH, c = idx - r * CH;
+            if (32 * CH % 64 != 0 && r >= 32) continue;
+            *reinterpret_cast<float4*>(slab + (int64_t)(mw + h * 32 + r) * p.N + nw + c * 4) =
+                *reinterpret_cast<const float4*>(strip + r * ROWF + c * 4);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // GEGLU variant of epilogue_rows: h * gelu(g) is formed in registers exactly as in epilogue_regs (value / gate tiles of a
 // pair sit in the same lane), staged, and written as [M, N/2] rows with 16-byte stores.
 template <int TM, int TN>
@@ -832,6 +863,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
             epilogue_rows_geglu<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
             return;
         }
+    }
+    if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+        __syncthreads();
+        constexpr int kStripS = 32 * (TN * 16 + 4);
+        epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        return;
     }
     if (rows_ok) {
         __syncthreads();  // every wave is done with the K-loop stages: the strips below overwrite them
