@@ -149,60 +149,66 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 // The slab (<= 128 KiB, host-checked) is read three times -- sum, centred sum of squares, normalise -- the second
 // and third time out of L2; no register array, so the kernel stays small and many workgroups share a CU.
-template <typename T>
+template <typename T, int VB>  // VB = bytes per access (4, 8 or 16): the widest that divides the group's row of C/G channels
 __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict__ X, T* __restrict__ Y, int HW, int C, int G,
                                                             float eps, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int silu) {
-    constexpr int EPW = sizeof(T) == 2 ? 2 : 1;  // elements per 4-byte word
+    constexpr int EP = VB / (int)sizeof(T);       // elements per access
+    constexpr int NW = VB / 4;                    // 32-bit words per access
+    typedef unsigned vec_t __attribute__((ext_vector_type(NW)));
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y;
-    const int cpg = C / G, wpr = cpg / EPW;       // words per pixel row of this group
-    const int total = HW * wpr;
-    const unsigned* Xw = reinterpret_cast<const unsigned*>(X + ((int64_t)b * HW) * C + (int64_t)g * cpg);
-    unsigned* Yw = reinterpret_cast<unsigned*>(Y + ((int64_t)b * HW) * C + (int64_t)g * cpg);
-    const int rw = C / EPW;                        // row stride in words
-    // item it = tid + 256 k -> (pixel, word-in-row), advanced incrementally (no division in the loops)
-    const int dq = kThreads / wpr, dr = kThreads - dq * wpr;
-    const int px0 = (int)threadIdx.x / wpr, j0 = (int)threadIdx.x - px0 * wpr;
+    const int cpg = C / G, vpr = cpg / EP;        // accesses per pixel row of this group
+    const int total = HW * vpr;
+    const T* Xg = X + ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    T* Yg = Y + ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    // item it = tid + 256 k -> (pixel, access-in-row), advanced incrementally (no division in the loops)
+    const int dq = kThreads / vpr, dr = kThreads - dq * vpr;
+    const int px0 = (int)threadIdx.x / vpr, j0 = (int)threadIdx.x - px0 * vpr;
+    auto unpack = [](const vec_t& w, float (&v)[EP]) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            if (sizeof(T) == 2) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+            else v[k] = __uint_as_float(w[k]);
+        }
+    };
     float s = 0.f;
     for (int it = threadIdx.x, px = px0, j = j0; it < total; it += kThreads) {
-        const unsigned w = Xw[(int64_t)px * rw + j];
-        if (EPW == 2) s += __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
-        else s += __uint_as_float(w);
+        float v[EP];
+        unpack(*reinterpret_cast<const vec_t*>(Xg + (int64_t)px * C + j * EP), v);
+#pragma unroll
+        for (int k = 0; k < EP; ++k) s += v[k];
         px += dq; j += dr;
-        if (j >= wpr) { j -= wpr; ++px; }
+        if (j >= vpr) { j -= vpr; ++px; }
     }
     const float n = (float)HW * (float)cpg;
     const float mean = block_sum_256(s, red) / n;
     float q = 0.f;
     for (int it = threadIdx.x, px = px0, j = j0; it < total; it += kThreads) {
-        const unsigned w = Xw[(int64_t)px * rw + j];
-        if (EPW == 2) {
-            const float a = __uint_as_float(w << 16) - mean, c = __uint_as_float(w & 0xffff0000u) - mean;
-            q += a * a + c * c;
-        } else {
-            const float a = __uint_as_float(w) - mean;
-            q += a * a;
-        }
+        float v[EP];
+        unpack(*reinterpret_cast<const vec_t*>(Xg + (int64_t)px * C + j * EP), v);
+#pragma unroll
+        for (int k = 0; k < EP; ++k) { const float a = v[k] - mean; q += a * a; }
         px += dq; j += dr;
-        if (j >= wpr) { j -= wpr; ++px; }
+        if (j >= vpr) { j -= vpr; ++px; }
     }
     const float rstd = rsqrtf(block_sum_256(q, red) / n + eps);
     for (int it = threadIdx.x, px = px0, j = j0; it < total; it += kThreads) {
-        const unsigned w = Xw[(int64_t)px * rw + j];
-        const int c0 = g * cpg + j * EPW;
-        if (EPW == 2) {
-            float a = (__uint_as_float(w << 16) - mean) * rstd * gamma[c0] + beta[c0];
-            float c = (__uint_as_float(w & 0xffff0000u) - mean) * rstd * gamma[c0 + 1] + beta[c0 + 1];
-            if (silu) { a = silu_f(a); c = silu_f(c); }
-            Yw[(int64_t)px * rw + j] = pack_bf16x2(a, c);
-        } else {
-            float a = (__uint_as_float(w) - mean) * rstd * gamma[c0] + beta[c0];
+        float v[EP];
+        unpack(*reinterpret_cast<const vec_t*>(Xg + (int64_t)px * C + j * EP), v);
+        const int c0 = g * cpg + j * EP;
+#pragma unroll
+        for (int k = 0; k < EP; ++k) {
+            float a = (v[k] - mean) * rstd * gamma[c0 + k] + beta[c0 + k];
             if (silu) a = silu_f(a);
-            Yw[(int64_t)px * rw + j] = __float_as_uint(a);
+            v[k] = a;
         }
+        vec_t o;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) o[k] = sizeof(T) == 2 ? pack_bf16x2(v[(2 * k) % EP], v[(2 * k + 1) % EP]) : __float_as_uint(v[k % EP]);
+        *reinterpret_cast<vec_t*>(Yg + (int64_t)px * C + j * EP) = o;
         px += dq; j += dr;
-        if (j >= wpr) { j -= wpr; ++px; }
+        if (j >= vpr) { j -= vpr; ++px; }
     }
 }
 
@@ -366,8 +372,19 @@ int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, in
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(G, B);
-    if (dtype == GMD_BF16) gn_fused_kernel<bf16_t><<<grid, kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, (int)HW, C, G, eps, gamma, beta, silu);
-    else gn_fused_kernel<float><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, (int)HW, C, G, eps, gamma, beta, silu);
+    // widest access that divides a group's channel row and keeps every access aligned (row stride C, group offset g*cpg)
+    const int esz = dtype == GMD_BF16 ? 2 : 4;
+    const auto ok = [&](int vb) {
+        return (cpg * esz) % vb == 0 && (C * esz) % vb == 0 && (reinterpret_cast<uintptr_t>(X) % vb) == 0 && (reinterpret_cast<uintptr_t>(Y) % vb) == 0;
+    };
+    const int vb = ok(16) ? 16 : ok(8) ? 8 : 4;
+#define GMD_GN_FUSED(T, VB) gn_fused_kernel<T, VB><<<grid, kThreads, 0, s>>>((const T*)X, (T*)Y, (int)HW, C, G, eps, gamma, beta, silu)
+    if (dtype == GMD_BF16) {
+        if (vb == 16) GMD_GN_FUSED(bf16_t, 16); else if (vb == 8) GMD_GN_FUSED(bf16_t, 8); else GMD_GN_FUSED(bf16_t, 4);
+    } else {
+        if (vb == 16) GMD_GN_FUSED(float, 16); else if (vb == 8) GMD_GN_FUSED(float, 8); else GMD_GN_FUSED(float, 4);
+    }
+#undef GMD_GN_FUSED
     GMD_CHECK_LAUNCH("gmd_groupnorm_fused");
     return GMD_OK;
 }

@@ -255,8 +255,12 @@ def groupnorm_apply(x, B, ss, silu):
     return y
 
 
-GN_FUSED_MAX_SLAB = 24 * 1024  # bytes of one (sample, group) slab up to which the single-launch kernel wins (tools/bench_gn.py:
-# 9-18 us vs ~24-30 us for the three-launch path on the 16x16 / 8x8 UNet levels; beyond ~40 KiB the strided re-reads lose)
+# bytes of one (sample, group) slab up to which the single-launch kernel wins (tools/bench_gn.py, MI355X): 5-21 us against
+# 14-27 us for the three-launch path on the 16x16 / 8x8 UNet levels.  The kernel walks one group's channels of every pixel,
+# so it needs long enough channel rows: with 16-byte accesses (C/G a multiple of 8 bf16) it wins up to 40 KiB, with 8- or
+# 4-byte accesses only up to 24 KiB; beyond that the strided re-reads lose to the row-contiguous split kernels.
+GN_FUSED_MAX_SLAB = 24 * 1024
+GN_FUSED_MAX_SLAB_VEC16 = 40 * 1024
 
 
 def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
@@ -267,7 +271,8 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
     HW = x.numel() // (B * C)
     epw = 2 if x.dtype == torch.bfloat16 else 1
     cpg = C // groups
-    if cpg % epw == 0 and HW * cpg * x.element_size() <= GN_FUSED_MAX_SLAB:
+    vec16 = (cpg * x.element_size()) % 16 == 0 and (C * x.element_size()) % 16 == 0
+    if cpg % epw == 0 and HW * cpg * x.element_size() <= (GN_FUSED_MAX_SLAB_VEC16 if vec16 else GN_FUSED_MAX_SLAB):
         y = torch.empty_like(x)
         check(lib().gmd_groupnorm_fused(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
                                         _ptr(_f32(beta, "beta")), int(silu), _stream()), "gmd_groupnorm_fused")
