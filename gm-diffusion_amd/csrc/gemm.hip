@@ -299,12 +299,12 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
                                               int z) {
-    static_assert(TM == 4, "two halves of two 16-row tiles");
+    static_assert(TM % 2 == 0, "halves of two 16-row tiles");
     constexpr int NCOL = TN * 16, ROWF = NCOL + 4, CH = NCOL / 8;
     constexpr int ITER = (32 * CH + 63) / 64;
     const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -665,6 +665,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         }
     }
 
+    // every path above ends on the stage-release barrier: the LDS stages are dead and can carry the epilogue strips
+    if constexpr (TM % 2 == 0 && (size_t)4 * 32 * (TN * 16 + 4) * 4 <= (size_t)2 * (BM + BN) * 128) {
+        const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
+                             (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
+                             (p.rowbias == nullptr || (p.ldrb & 3) == 0);
+        if (rows_ok) {
+            __syncthreads();
+            epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * (32 * (TN * 16 + 4)), m0 + wr * (BM / 2), n0 + wc * (BN / 2),
+                                  lane, z);
+            return;
+        }
+    }
     epilogue_regs<TM, TN>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 2), frow, fq, z, ks);
 }
 
