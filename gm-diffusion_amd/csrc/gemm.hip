@@ -669,7 +669,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     if constexpr (TM % 2 == 0 && (size_t)4 * 32 * (TN * 16 + 4) * 4 <= (size_t)2 * (BM + BN) * 128) {
         const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
                              (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
-                             (p.rowbias == nullptr || (p.ldrb & 3) == 0);
+                             (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
         if (rows_ok) {
             __syncthreads();
             epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * (32 * (TN * 16 + 4)), m0 + wr * (BM / 2), n0 + wc * (BN / 2),
@@ -867,9 +868,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
     // block-uniform choice: full bf16 tile, plain epilogue -> row-contiguous stores through LDS
     const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
                          (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
-                         (p.rowbias == nullptr || (p.ldrb & 3) == 0);
+                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     if constexpr (TN % 2 == 0) {
-        if (p.act == GMD_ACT_GEGLU && !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 && (p.sC & 7) == 0) {
+        if (p.act == GMD_ACT_GEGLU && !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
             __syncthreads();
             constexpr int kStripG = 32 * (TN * 8 + 4);
             epilogue_rows_geglu<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
@@ -1093,6 +1096,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     GMD_REQUIRE(lda % vec == 0 && ldw % vec == 0 && strideA % vec == 0 && strideW % vec == 0,
                 "gmd_gemm_nt: lda/ldw/strides must be multiples of %d elements", vec);
     GMD_REQUIRE(A && W && C && gmd_aligned16(A) && gmd_aligned16(W) && gmd_aligned16(C), "gmd_gemm_nt: null or unaligned pointer");
+    GMD_REQUIRE(bias == nullptr || gmd_aligned16(bias), "gmd_gemm_nt: bias must be 16-byte aligned (it is read with float4 loads)");
     GMD_REQUIRE(rowbias == nullptr || rows_per_group > 0, "gmd_gemm_nt: rows_per_group must be positive");
     GMD_REQUIRE(residual == nullptr || (ldr >= N && gmd_aligned16(residual)), "gmd_gemm_nt: bad residual");
     GMD_REQUIRE(residual == nullptr || out_dtype == dtype || dtype == GMD_F32, "gmd_gemm_nt: residual needs out_dtype == dtype");
@@ -1130,6 +1134,7 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     const int kmul = dtype == GMD_BF16 ? 64 : 16;
     GMD_REQUIRE(Cin % kmul == 0, "gmd_conv3x3: Cin=%d must be a multiple of %d (pad the channels)", Cin, kmul);
     GMD_REQUIRE(X && Wt && Y && gmd_aligned16(X) && gmd_aligned16(Wt) && gmd_aligned16(Y), "gmd_conv3x3: null or unaligned pointer");
+    GMD_REQUIRE(bias == nullptr || gmd_aligned16(bias), "gmd_conv3x3: bias must be 16-byte aligned (it is read with float4 loads)");
     GMD_REQUIRE(residual == nullptr || gmd_aligned16(residual), "gmd_conv3x3: unaligned residual");
     GMD_REQUIRE(residual == nullptr || out_dtype == dtype, "gmd_conv3x3: residual needs out_dtype == dtype");
     int Hout, Wout, pad_lo;
