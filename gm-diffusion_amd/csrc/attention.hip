@@ -381,20 +381,33 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
         l_tot = l_run + __shfl_xor(l_run, 32, 64);
     }
     const float inv = 1.0f / l_tot;
-    if (qvalid) {
-        bf16_t* Ob = p.O + (int64_t)b * p.sO + (int64_t)q * p.ldo + (int64_t)head * D;
+    // Row-contiguous output through LDS (the stages are dead after the last tile's barrier).  Out of the registers a store
+    // instruction would cover 32 rows x 16 bytes, and the store path is transaction-bound (see gemm.hip, epilogue_rows);
+    // instead every wave packs its 32 x D tile into a private strip and writes whole D*2-byte head segments, 16 bytes a lane.
+    constexpr int SROW = D * 2 + 16;                 // strip row stride in bytes (pad: spreads the rows over the banks)
+    unsigned char* strip = smem + wid * (32 * SROW);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * dt + 8 * g + 4 * hh;
-                if (d0 < D) {
-                    uint2 w;
-                    w.x = pack_bf16x2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
-                    w.y = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
-                    *reinterpret_cast<uint2*>(Ob + d0) = w;
-                }
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 32 * dt + 8 * g + 4 * hh;
+            if (d0 < D) {
+                uint2 w;
+                w.x = pack_bf16x2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
+                w.y = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(strip + r * SROW + d0 * 2) = w;
             }
+        }
+    __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS: a compiler fence only
+    constexpr int CH = D / 8;         // 16-byte chunks per query row
+    const int q0w = qb * 128 + wid * 32;
+    bf16_t* Ow = p.O + (int64_t)b * p.sO + (int64_t)q0w * p.ldo + (int64_t)head * D;
+#pragma unroll
+    for (int t = 0; t < (32 * CH + 63) / 64; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / CH, cc = idx - rr * CH;
+        if (rr < 32 && q0w + rr < p.Nq)
+            *reinterpret_cast<uint4*>(Ow + (int64_t)rr * p.ldo + cc * 8) = *reinterpret_cast<const uint4*>(strip + rr * SROW + cc * 16);
     }
 }
 
@@ -426,8 +439,8 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
     GMD_REQUIRE((int64_t)((Nq + 127) / 128) * H * B < (1ll << 31), "gmd_attention: grid too large");
     GMD_REQUIRE(Q && K && Vt && O, "gmd_attention: null pointer");
     GMD_REQUIRE(gmd_aligned16(Q) && gmd_aligned16(K) && gmd_aligned16(Vt) && gmd_aligned16(O), "gmd_attention: pointers must be 16-byte aligned");
-    GMD_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "gmd_attention: leading dimensions must be multiples of 8 (ldo: 4)");
-    GMD_REQUIRE(strideQ % 8 == 0 && strideK % 8 == 0 && strideVt % 8 == 0 && strideO % 4 == 0, "gmd_attention: batch strides must be multiples of 8");
+    GMD_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0, "gmd_attention: leading dimensions must be multiples of 8");
+    GMD_REQUIRE(strideQ % 8 == 0 && strideK % 8 == 0 && strideVt % 8 == 0 && strideO % 8 == 0, "gmd_attention: batch strides must be multiples of 8");
     GMD_REQUIRE((int64_t)Nk * ldk < (1ll << 30) && (int64_t)D * ldvt < (1ll << 30), "gmd_attention: K / V^T slab of one head exceeds 2 GiB");
     GMD_REQUIRE(ldvt >= ((Nk + 7) / 8) * 8, "gmd_attention: ldvt=%lld must cover Nk=%d rounded up to 8", (long long)ldvt, Nk);
     GMD_REQUIRE(ldq >= (int64_t)H * D && ldk >= (int64_t)H * D && ldo >= (int64_t)H * D, "gmd_attention: row stride smaller than H*D");
