@@ -45,6 +45,7 @@ SIGNATURES = {
     "gmd_groupnorm_nsplit": [L],
     "gmd_groupnorm_stats": [P, I, I, L, I, I, F, P, P, P, P, P],
     "gmd_groupnorm_apply": [P, P, I, I, L, I, P, I, P],
+    "gmd_groupnorm_split": [P, P, I, I, L, I, I, F, P, P, P, I, P],
     "gmd_groupnorm_fused": [P, P, I, I, L, I, I, F, P, P, I, P],
     "gmd_layernorm": [P, P, I, L, I, P, P, F, P],
     "gmd_geglu": [P, P, I, L, I, P],

@@ -277,7 +277,12 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
         check(lib().gmd_groupnorm_fused(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
                                         _ptr(_f32(beta, "beta")), int(silu), _stream()), "gmd_groupnorm_fused")
         return y
-    return groupnorm_apply(x, B, groupnorm_scale_shift(x, B, groups, gamma, beta, eps), silu)
+    nsplit = lib().gmd_groupnorm_nsplit(HW)
+    ws = torch.empty(B * nsplit * groups * 2, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check(lib().gmd_groupnorm_split(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
+                                    _ptr(_f32(beta, "beta")), _ptr(ws), int(silu), _stream()), "gmd_groupnorm_split")
+    return y
 
 
 def groupnorm_split(x, B, groups, gamma, beta, eps, silu=False):

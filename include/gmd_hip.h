@@ -203,6 +203,11 @@ int gmd_groupnorm_stats(const void* X, int dtype, int B, int64_t HW, int C, int 
                         const float* gamma, const float* beta, float* workspace,
                         float* scale_shift, gmd_stream_t stream);
 /* Y = [silu](X*scale+shift) */
+/* GroupNorm(+SiLU) in two launches for slabs too large for gmd_groupnorm_fused: partial sums per (sample, row split, group)
+ * into `workspace` (same size as for gmd_groupnorm_stats), then an apply kernel whose workgroups fold the partials of their
+ * sample themselves (deterministic order) -- no separate finalize launch, no scale_shift tensor. */
+int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps,
+                        const float* gamma, const float* beta, float* workspace, int silu, gmd_stream_t stream);
 int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, int C,
                         const float* scale_shift, int silu, gmd_stream_t stream);
 /* GroupNorm(+SiLU) in ONE launch: one workgroup per (sample, group) over the group's [HW][C/G] slab (exact two-pass

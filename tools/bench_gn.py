@@ -19,6 +19,7 @@ for B in (8, 4):
         ga, be = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
         slab = HW * (C // 32) * 2
         ts = timeit(lambda: ops.groupnorm_split(x, B, 32, ga, be, 1e-5, True))
+        t2 = timeit(lambda: ops.groupnorm(x, B, 32, ga, be, 1e-5, True))
         tf = float("nan")
         if slab <= 128 * 1024:
             y = torch.empty_like(x)
@@ -26,4 +27,4 @@ for B in (8, 4):
             def f():
                 check(lib().gmd_groupnorm_fused(x.data_ptr(), y.data_ptr(), 1, B, HW, C, 32, 1e-5, ga.data_ptr(), be.data_ptr(), 1, torch.cuda.current_stream().cuda_stream), "f")
             tf = timeit(f)
-        print(f"B={B} HW={HW} C={C} slab={slab//1024}KB split={ts:6.1f}us fused={tf:6.1f}us")
+        print(f"B={B} HW={HW} C={C} slab={slab//1024}KB split3={ts:6.1f}us fused={tf:6.1f}us dispatch={t2:6.1f}us")
