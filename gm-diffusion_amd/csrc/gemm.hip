@@ -991,6 +991,12 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
         if (ks > 16) ks = 16;
         if (ks > 1 && (int64_t)ks * M * N * (int64_t)sizeof(float) <= ws_bytes) pl.ksplit = ks;
     }
+    // batched, operand-swapped projections (V^T[b] = W_v x_b^T: M = channels <= 640, N = tokens): 128-row tiles leave a
+    // ragged third row block at M = 320 and lose to 64x64 tiles even at M = 640 (tools/bench_vt.py: 27.9 -> 18.4 us, 17.2 -> 15.7 us)
+    if (pl.ksplit == 1 && batch > 1 && M <= 640 && pl.bm == 128 && !pair_tiles && !(fbm && fbn)) {
+        pl.bm = 64;
+        pl.bn = 64;
+    }
     if (pl.ksplit == 1 && tiles < 256 && pl.bm == 128 && !(fbm && fbn)) {  // cannot fill the chip: 4-5x more, smaller tiles
         pl.bm = 64;
         pl.bn = 64;
