@@ -83,13 +83,29 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[4]) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// Wave-wide reductions on the data-parallel-primitive (DPP) path: quad permutes, then the two row mirrors, then the four
+// 16-lane rows are met through v_readlane -- ~11 short VALU / SALU instructions instead of six ds_bpermute round trips
+// through the LDS crossbar (__shfl_xor), whose dependent latency dominated the one-row-per-wave LayerNorm.  Fixed order:
+// deterministic; every lane returns the same value.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror: the other quad of each group of 8
+    v += dpp_f32<0x140>(v);  // row_mirror: the other half of each row of 16
+    const int iv = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    const int iv = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
 }

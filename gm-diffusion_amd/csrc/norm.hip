@@ -280,50 +280,60 @@ __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers, exact two-pass variance.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MAXCH>
+template <typename T, int MAXCH, int ROWS>
 __global__ __launch_bounds__(kThreads) void layernorm_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps) {
+    // one wave per ROWS consecutive rows, each row held in registers (exact two-pass variance); the loads of all ROWS rows
+    // are issued before the first reduction, so a wave keeps ROWS x MAXCH 16-byte loads in flight instead of MAXCH
     constexpr int V = Elem<T>::kVec;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= rows) return;
     const int CV = C / V;
-    float v[MAXCH][V];
-    float s = 0.0f;
+    float v[ROWS][MAXCH][V];
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int chunk = lane + 64 * k;
-        if (chunk < CV) {
-            load_vec(X + row * C + (int64_t)chunk * V, v[k]);
+    for (int rr = 0; rr < ROWS; ++rr)
 #pragma unroll
-            for (int j = 0; j < V; ++j) s += v[k][j];
-        } else {
+        for (int k = 0; k < MAXCH; ++k) {
+            const int chunk = lane + 64 * k;
+            if (chunk < CV && row0 + rr < rows) {
+                load_vec(X + (row0 + rr) * C + (int64_t)chunk * V, v[rr][k]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < V; ++j) v[k][j] = 0.0f;
-        }
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float s2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        if (lane + 64 * k < CV) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) { const float d = v[k][j] - mean; s2 += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
-#pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int chunk = lane + 64 * k;
-        if (chunk < CV) {
-            float o[V];
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const int c = chunk * V + j;
-                o[j] = (v[k][j] - mean) * rstd * gamma[c] + beta[c];
+                for (int j = 0; j < V; ++j) v[rr][k][j] = 0.0f;
             }
-            store_vec(Y + row * C + (int64_t)chunk * V, o);
+        }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        if (row0 + rr >= rows) break;  // wave-uniform
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k)
+#pragma unroll
+            for (int j = 0; j < V; ++j) s += v[rr][k][j];
+        const float mean = wave_sum(s) / (float)C;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            if (lane + 64 * k < CV) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { const float d = v[rr][k][j] - mean; s2 += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int chunk = lane + 64 * k;
+            if (chunk < CV) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const int c = chunk * V + j;
+                    o[j] = (v[rr][k][j] - mean) * rstd * gamma[c] + beta[c];
+                }
+                store_vec(Y + (row0 + rr) * C + (int64_t)chunk * V, o);
+            }
         }
     }
 }
@@ -497,10 +507,16 @@ int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C, const 
     const int grid = (int)((rows + 3) / 4);
     if (dtype == GMD_BF16) {
         GMD_REQUIRE(C % 8 == 0, "gmd_layernorm: C=%d must be a multiple of 8", C);
-        layernorm_kernel<bf16_t, 4><<<grid, kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
+        // narrow rows (one 16-byte chunk per lane) and many of them: four rows per wave keep four loads in flight
+        if (C <= 512 && rows >= 8192)
+            layernorm_kernel<bf16_t, 1, 4><<<(int)((rows + 15) / 16), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
+        else if (C <= 1024 && rows >= 4096)
+            layernorm_kernel<bf16_t, 2, 2><<<(int)((rows + 7) / 8), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
+        else
+            layernorm_kernel<bf16_t, 4, 1><<<grid, kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
     } else if (dtype == GMD_F32) {
         GMD_REQUIRE(C % 4 == 0, "gmd_layernorm: C=%d must be a multiple of 4", C);
-        layernorm_kernel<float, 8><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, rows, C, gamma, beta, eps);
+        layernorm_kernel<float, 8, 1><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, rows, C, gamma, beta, eps);
     } else {
         GMD_REQUIRE(false, "gmd_layernorm: bad dtype %d", dtype);
     }
