@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
         float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[0][i]), st[1][i]);  // v_max3_f32
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = half_swap_max(mx);
         float alpha;
         if constexpr (LAG) {
             // st is already log2(p) against the stabiliser of the previous tile: exp2 applies directly.  The stabiliser
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
                     if (key < p.Nk && !(CAUSAL && key > q)) mx = fmaxf(mx, s0[i]);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = half_swap_max(mx);
             set_stabiliser((float)(__bf16)mx);
         }
         for (int kt = 0; kt < ntiles; ++kt) tile(kt, kt & 1, std::true_type{});
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
         // row D of O^T: tile D/32, register 4*((D%32)/8) of the lanes with hh == 0 (D is a multiple of 8)
         l_tot = __shfl(ot[D / 32][4 * ((D % 32) / 8)], r, 64);
     } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        l_tot = half_swap_sum(l_run);
     }
     const float inv = 1.0f / l_tot;
     // Row-contiguous output through LDS (the stages are dead after the last tile's barrier).  Out of the registers a store

@@ -100,6 +100,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
            (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
 }
+// value of lane l combined with lane l ^ 32 (the two halves of a wave) through v_permlane32_swap: no LDS crossbar trip
+__device__ __forceinline__ float half_swap_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_f32<0xB1>(v));
     v = fmaxf(v, dpp_f32<0x4E>(v));
