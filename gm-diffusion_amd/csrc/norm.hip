@@ -381,7 +381,9 @@ inline int grid_for(int64_t n) {
 extern "C" {
 
 int gmd_groupnorm_nsplit(int64_t HW) {
-    int64_t n = HW / 32;  // >= 32 pixels per block; B * nsplit blocks should cover the 256 CUs several times
+    // >= 32 pixels per block (64 from 64x64 latents up: the apply workgroups fold these partials again, and the coarser split
+    // wins there -- tools/bench_gn.py); B * nsplit blocks should cover the 256 CUs several times
+    int64_t n = HW >= 4096 ? HW / 64 : HW / 32;
     if (n < 1) n = 1;
     if (n > 256) n = 256;
     return (int)n;
