@@ -303,6 +303,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
     constexpr int NCOL = TN * 16, ROWF = NCOL + 4, CH = NCOL / 8;
     constexpr int ITER = (32 * CH + 63) / 64;
     const int frow = lane & 15, fq = lane >> 4;
+    // row-bias group (sample) of the wave tile's first row: ONE division per wave instead of one per stored item; a group
+    // of at least 64 rows can change at most once inside the 64-row wave tile
+    int g0 = 0, grem = 0;
+    if (p.rowbias) {
+        g0 = mw / p.rows_per_group;
+        grem = mw - g0 * p.rows_per_group;
+    }
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
@@ -329,7 +336,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
                 for (int e = 0; e < 4; ++e) { add[2 * e] = __uint_as_float(ww[e] << 16); add[2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
             }
             if (p.rowbias) {
-                const float* rb = p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb + n;
+                const int ro = h * 32 + r;  // row offset inside the wave tile
+                const int grp = p.rows_per_group >= 64 ? g0 + (grem + ro >= p.rows_per_group ? 1 : 0) : m / p.rows_per_group;
+                const float* rb = p.rowbias + (int64_t)grp * p.ldrb + n;
                 const float4 t0 = *reinterpret_cast<const float4*>(rb), t1 = *reinterpret_cast<const float4*>(rb + 4);
                 add[0] += t0.x; add[1] += t0.y; add[2] += t0.z; add[3] += t0.w; add[4] += t1.x; add[5] += t1.y; add[6] += t1.z; add[7] += t1.w;
             }
