@@ -494,10 +494,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         if (CONV) {
             if (pv[i]) {
                 const int hw = p.Hout * p.Wout;
-                pb[i] = m / hw;
-                const int rem = m - pb[i] * hw;
-                py[i] = rem / p.Wout;
-                px[i] = rem - py[i] * p.Wout;
+                if (((hw & (hw - 1)) | (p.Wout & (p.Wout - 1))) == 0) {  // power-of-two feature maps (every SD-1.5 level): shifts
+                    const int sh = __builtin_ctz(hw), sw = __builtin_ctz(p.Wout);
+                    pb[i] = m >> sh;
+                    const int rem = m & (hw - 1);
+                    py[i] = rem >> sw;
+                    px[i] = rem & (p.Wout - 1);
+                } else {
+                    pb[i] = m / hw;
+                    const int rem = m - pb[i] * hw;
+                    py[i] = rem / p.Wout;
+                    px[i] = rem - py[i] * p.Wout;
+                }
             }
             aoff[i] = kOOB;
         } else {
@@ -746,10 +754,18 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(c
         if (CONV) {
             if (pv[i]) {
                 const int hw = p.Hout * p.Wout;
-                pb[i] = m / hw;
-                const int rem = m - pb[i] * hw;
-                py[i] = rem / p.Wout;
-                px[i] = rem - py[i] * p.Wout;
+                if (((hw & (hw - 1)) | (p.Wout & (p.Wout - 1))) == 0) {  // power-of-two feature maps (every SD-1.5 level): shifts
+                    const int sh = __builtin_ctz(hw), sw = __builtin_ctz(p.Wout);
+                    pb[i] = m >> sh;
+                    const int rem = m & (hw - 1);
+                    py[i] = rem >> sw;
+                    px[i] = rem & (p.Wout - 1);
+                } else {
+                    pb[i] = m / hw;
+                    const int rem = m - pb[i] * hw;
+                    py[i] = rem / p.Wout;
+                    px[i] = rem - py[i] * p.Wout;
+                }
             }
             aoff[i] = kOOB;
         } else {
