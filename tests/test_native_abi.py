@@ -54,6 +54,29 @@ def test_no_cpu_fallback():
         apply_gm_to_sdr(torch.zeros(1, 3, 2, 2), torch.zeros(1, 3, 2, 2))
     with pytest.raises(HipExtensionError):
         hip_ops.gemm_nt(torch.zeros(64, 64), torch.zeros(64, 64))
+    z = torch.zeros(1, 4, 8, 8)
+    host_calls = [
+        lambda: hip_ops.conv3x3(torch.zeros(1, 64, 64), torch.zeros(64, 576), 1, 8, 8),
+        lambda: hip_ops.attention(torch.zeros(1, 64, 64), torch.zeros(1, 64, 64), torch.zeros(1, 64, 64), 2, 64, 1.0),
+        lambda: hip_ops.groupnorm(torch.zeros(1, 64, 64), 1, 8, torch.ones(64), torch.zeros(64), 1e-5),
+        lambda: hip_ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64)),
+        lambda: hip_ops.embedding_lookup(torch.zeros(1, 4, dtype=torch.long), torch.zeros(10, 8), torch.zeros(4, 8)),
+        lambda: hip_ops.latent_step(z, z, 0, (1.0, 0.5, 1.0, 1.0, 0.0), False, 1.0),
+        lambda: hip_ops.dpm_step(z, z, 1, (0.5, 0.9, 0.9, -0.1, -0.05, 0.0, 1.0, 0.0), False, 1.0),
+        lambda: hip_ops.discretize_u16(torch.zeros(8)),
+        lambda: hip_ops.rgbe_encode(torch.zeros(4, 3)),
+    ]
+    for call in host_calls:  # every front-end op refuses host tensors: there is no CPU path to fall back to
+        with pytest.raises(HipExtensionError):
+            call()
+    from gm_diffusion.components import CLIPTextModel, UNet2DConditionModel
+
+    with pytest.raises(HipExtensionError):
+        UNet2DConditionModel(block_out_channels=(32, 32, 32, 32), cross_attention_dim=32, attention_head_dim=2, norm_num_groups=8).init_random(0)(
+            torch.zeros(1, 4, 8, 8), 1, encoder_hidden_states=torch.zeros(1, 77, 32))
+    with pytest.raises(HipExtensionError):
+        CLIPTextModel(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2).init_random(0)(
+            torch.zeros(1, 77, dtype=torch.long))
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
