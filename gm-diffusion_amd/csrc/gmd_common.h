@@ -91,6 +91,20 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// sum over each aligned group of 8 lanes (every lane of the group returns it), doubles, on the DPP path
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double group8_sum(double v) {
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __re
                 s += o.x; s2 += o.y;
             }
         }
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s = group8_sum(s);
+        s2 = group8_sum(s2);
         if (g < G && sub == 0) {
             const double n = (double)HW * cpg;
             const double mean = s / n;
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
                 s += o.x; s2 += o.y;
             }
         }
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s = group8_sum(s);
+        s2 = group8_sum(s2);
         if (g < G && sub == 0) {
             const double n = (double)HW * cpg;
             const double mean = s / n;
