@@ -592,3 +592,65 @@ def test_empty_inputs_are_no_ops():
     z = torch.empty(0, 4, 8, 8, device=DEV)
     eps, xp, x0 = o.latent_step(z, z, 0, (1.0, 0.5, 1.0, 1.0, 0.0), False, 1.0, want_x0=True)
     assert xp.numel() == 0 and x0.numel() == 0
+
+
+def test_gemm_conv_epilogue_fuzz():
+    """Seeded sweep over shapes that straddle every epilogue path of the bf16 kernels (row-contiguous LDS epilogue on full
+    tiles, register epilogue on ragged edges / float32 outputs, split-K slabs, 64x64 kernel, batched launches) with all
+    combinations of bias / row bias (group sizes around the 64-row wave tile) / residual / activation / alpha."""
+    o = ops()
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(2024)
+    acts = [(o.ACT_NONE, lambda z: z), (o.ACT_SILU, F.silu), (o.ACT_QUICK_GELU, lambda z: z * torch.sigmoid(1.702 * z))]
+    cases = 0
+    for _ in range(36):
+        M = int(rng.choice([128, 256, 384, 640, 1000, 1024, 2048, 4096, 16384]))
+        N = int(rng.choice([64, 128, 160, 320, 328, 640, 1280]))
+        K = int(rng.choice([64, 128, 320, 640, 1536, 2560]))
+        if M * N * K > 16384 * 640 * 640:
+            continue
+        use_bias, use_rb, use_res = (bool(v) for v in rng.integers(0, 2, 3))
+        act, fn = acts[int(rng.integers(0, 3))]
+        alpha = float(rng.choice([1.0, 0.5]))
+        out_f32 = bool(rng.integers(0, 4) == 0) and not use_res
+        a = torch.randn(M, K, generator=g).bfloat16()
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+        ref = alpha * (a.double() @ w.double().t())
+        kw = {}
+        if use_bias:
+            b = torch.randn(N, generator=g)
+            kw["bias"] = b.to(DEV)
+            ref = ref + b.double()
+        if use_rb:
+            rpg = int(rng.choice([16, 48, 64, 100, 256, M]))
+            rb = torch.randn((M + rpg - 1) // rpg, N, generator=g)
+            kw.update(rowbias=rb.to(DEV), rows_per_group=rpg)
+            ref = ref + rb.double().repeat_interleave(rpg, 0)[:M]
+        if use_res:
+            r = torch.randn(M, N, generator=g).bfloat16()
+            kw["residual"] = r.to(DEV)
+            ref = ref + r.double()
+        got = o.gemm_nt(a.to(DEV), w.to(DEV), alpha=alpha, act=act, out_dtype=torch.float32 if out_f32 else None, **kw)
+        assert got.shape == (M, N)
+        assert rel_err(got.float(), fn(ref)) < 1.2e-2, (M, N, K, use_bias, use_rb, use_res, act, alpha, out_f32)
+        cases += 1
+    for _ in range(14):  # conv3x3: spatial sizes around the tile, stride / upsample, row bias = per-sample time embedding
+        B = int(rng.choice([1, 2, 3, 8]))
+        H = int(rng.choice([8, 12, 16, 32, 64]))
+        W = int(rng.choice([8, 16, 20, 32, 64]))
+        ci, co = int(rng.choice([64, 128, 320])), int(rng.choice([64, 160, 320]))
+        mode = int(rng.integers(0, 3))  # 0 plain, 1 stride 2, 2 upsample
+        x = torch.randn(B, ci, H, W, generator=g).bfloat16()
+        wt = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)).bfloat16()
+        b = torch.randn(co, generator=g)
+        tb = torch.randn(B, co, generator=g)
+        xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if mode == 2 else x.double()
+        ref = F.conv2d(xin, wt.double(), b.double(), stride=2 if mode == 1 else 1, padding=1) + tb.double()[:, :, None, None]
+        xl = x.permute(0, 2, 3, 1).reshape(B, H * W, ci).contiguous().to(DEV)
+        wl = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous().to(DEV)
+        y, ho, wo = o.conv3x3(xl, wl, B, H, W, bias=b.to(DEV), rowbias=tb.to(DEV), stride=2 if mode == 1 else 1, upsample=mode == 2)
+        assert (ho, wo) == tuple(ref.shape[-2:])
+        got = y.float().cpu().view(B, ho, wo, co).permute(0, 3, 1, 2)
+        assert rel_err(got, ref) < 1.2e-2, (B, H, W, ci, co, mode)
+        cases += 1
+    assert cases >= 40
