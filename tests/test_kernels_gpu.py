@@ -654,3 +654,51 @@ def test_gemm_conv_epilogue_fuzz():
         assert rel_err(got, ref) < 1.2e-2, (B, H, W, ci, co, mode)
         cases += 1
     assert cases >= 40
+
+
+def test_attention_and_norm_fuzz():
+    """Seeded sweep: attention over head dims / ragged token counts / fused-QK buffers, GroupNorm over both kernels' ranges
+    (fused with 16/8/4-byte rows, two-launch split), LayerNorm over the one- / two- / four-row variants."""
+    o = ops()
+    rng = np.random.default_rng(7)
+    g = torch.Generator().manual_seed(7)
+    for _ in range(14):
+        D = int(rng.choice([32, 40, 64, 80, 160]))
+        H = int(rng.choice([1, 2, 8]))
+        B = int(rng.choice([1, 2, 3]))
+        Nq = int(rng.choice([1, 31, 64, 130, 256, 777]))
+        self_attn = bool(rng.integers(0, 2))
+        Nk = Nq if self_attn else int(rng.choice([1, 7, 77, 154, 300]))
+        C = H * D
+        k = torch.randn(B, Nk, C, generator=g).bfloat16()
+        v = torch.randn(B, Nk, C, generator=g).bfloat16()
+        ld = (Nk + 7) // 8 * 8
+        vt = torch.full((B, C, ld), float("nan")).bfloat16()
+        vt[:, :, :Nk] = v.transpose(1, 2)
+        if self_attn:  # q and k as two column blocks of one fused projection buffer
+            qk = torch.randn(B, Nq, 2 * C, generator=g).bfloat16()
+            qk[..., C:] = k
+            q = qk[..., :C]
+            got = o.attention(qk.to(DEV), qk.to(DEV), vt.to(DEV), H, Nk, D ** -0.5, k_col=C)
+        else:
+            q = torch.randn(B, Nq, C, generator=g).bfloat16()
+            got = o.attention(q.to(DEV), k.to(DEV), vt.to(DEV), H, Nk, D ** -0.5)
+        ref = _attn_ref(q, k, v, H, D ** -0.5)
+        assert torch.isfinite(got.float()).all()
+        assert rel_err(got.float(), ref) < 1.3e-2, (D, H, B, Nq, Nk, self_attn)
+    for _ in range(12):
+        B = int(rng.choice([1, 2, 4]))
+        HW = int(rng.choice([16, 64, 100, 256, 1024, 4096]))
+        C = int(rng.choice([64, 320, 640, 960, 1280, 1920]))
+        silu = bool(rng.integers(0, 2))
+        x = (torch.randn(B, HW, C, generator=g) * 2 + 0.5).bfloat16()
+        ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        y = F.group_norm(x.float().transpose(1, 2), 32, ga, be, 1e-5)
+        y = (F.silu(y) if silu else y).transpose(1, 2)
+        got = o.groupnorm(x.to(DEV), B, 32, ga.to(DEV), be.to(DEV), 1e-5, silu=silu)
+        assert rel_err(got.float(), y) < 1e-2, ("gn", B, HW, C, silu)
+    for rows, C in [(5, 64), (300, 320), (8192, 320), (9000, 320), (4096, 640), (4100, 1024), (70, 1280), (8192, 512)]:
+        x = (torch.randn(rows, C, generator=g) * 3 - 1).bfloat16()
+        ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        got = o.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), 1e-5)
+        assert rel_err(got.float(), F.layer_norm(x.float(), (C,), ga, be, 1e-5)) < 1e-2, ("ln", rows, C)
