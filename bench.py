@@ -9,16 +9,22 @@ One "step" = one pass of the hot path over one batch of synthetic prompts:
   synthetic (no checkpoint exists offline) -- BASELINE.md §2/§3.
 
 N=1 workload = BASELINE.json configs[1]: SD-v1-5 dual-UNet, 512x512, 50 PNDM steps, bf16, batch 4.
-N>1 (launched by torch.distributed.run, one rank per GPU over RCCL): weak scaling, batch 4 per rank;
-rank 0 builds the full-batch embeddings/latents, broadcasts them, every rank denoises its slice.
+N>1: one rank per GPU over RCCL, weak scaling at `--batch` prompts per rank (or `--global-batch G` = G/N per rank:
+`--gpus 8 --global-batch 64` is BASELINE.json configs[2]); rank 0 builds the full-batch embeddings / latents and
+broadcasts them, every rank denoises its slice.  Launched either by `torch.distributed.run` (RANK / WORLD_SIZE in the
+environment) or bare as `python bench.py --gpus N`: the parent then starts the N ranks itself as child processes BEFORE
+anything touches the GPU and relays rank 0's line.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with
-  "roofline":     dominant kernel, algorithmic FLOPs / HIP-event-measured time in the timed region,
-  "cpu_baseline": the CPU oracle (a port, NOT diffusers) timed on this box's host cores on a bounded sample.
+  "roofline":     the kind with the largest measured time: algorithmic FLOPs (or bytes) / HIP-event time,
+  "kernels":      the same per kind, each with its fraction of the MFMA (2.5 PFLOP/s bf16) or HBM (8 TB/s) peak,
+  "cpu_baseline": the CPU oracle (a port, NOT diffusers) timed on this box's host cores on a bounded sample,
+  "latent_rms_vs_f32": drift of the benchmarked precision against the float32 HIP path on a short fixed run.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,11 +33,20 @@ for _p in (ROOT, os.path.join(ROOT, "gm-diffusion_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+F32_VECTOR_PEAK_TFLOPS = 157.3   # float32 parity path (FMA kernels)
 HBM_PEAK_GBPS = 8000.0
+MFMA_KINDS = ("conv3x3", "gemm_nt", "attention")
+KIND_KERNEL = {
+    "conv3x3": "gmd_conv3x3 (gemm_ring_kernel<CONV=true> + splitk_reduce: implicit-GEMM conv3x3, 49.6% of UNet / 96.8% of VAE FLOPs)",
+    "gemm_nt": "gmd_gemm_nt (gemm_ring_kernel / gemm_bf16_kernel<CONV=false> + splitk_reduce: Linear / conv1x1 / GEGLU projections)",
+    "attention": "gmd_attention (attn_fwd_kernel<D>: fused QK^T + softmax + PV, algorithmic head dim)",
+    "groupnorm": "gmd_groupnorm_fused / gmd_groupnorm_split (GroupNorm + SiLU)",
+    "layernorm": "gmd_layernorm",
+    "concat": "gmd_concat_channels (skip connections)",
+    "hdr_tail": "gmd_hdr_tail (denorm/clamp + u8 + Eq. 1 + /(qmax+1) + u16)",
+}
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -39,57 +54,101 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="prompts per GPU")
+    ap.add_argument("--batch", type=int, default=4, help="prompts per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0, help="total prompts over all GPUs (overrides --batch; must divide by the GPU count)")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--unet", default="sd15", choices=["sd15", "tiny"], help="tiny = structural smoke config (not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scheduler", default="pndm", choices=["pndm", "dpm++"],
-                    help="pndm = BASELINE.json's metric; dpm++ = the DPM-Solver++ swap of formal_improved.py:195 (side measurement)")
-    ap.add_argument("--event-lead-ms", type=float, default=0.0, help="device-side delay queued before the instrumented step")
+    ap.add_argument("--scheduler", default="pndm", choices=["pndm", "dpm++", "ddpm"],
+                    help="pndm = BASELINE.json's metric; dpm++ / ddpm = the schedulers the reference's scripts construct (side measurements)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the GM UNet on the SDR stream instead of a second HIP stream")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying captured HIP graphs")
+    ap.add_argument("--no-drift", action="store_true", help="skip the short bf16-vs-float32 drift measurement")
+    ap.add_argument("--drift-steps", type=int, default=10)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (a 1-GPU box owns 16 cores)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--checksum", action="store_true", help="add sha256 of the u16 HDR codes of the last step to the line (sharding tests)")
     return ap.parse_args()
 
 
-def cpu_baseline(res, steps, cores_hint=None):
-    """Time the CPU oracle on a bounded sample: ONE SD-1.5 UNet evaluation (batch 1) and ONE VAE decode at the bench
-    resolution, float32, all host cores; extrapolate to one HDR image = (steps+1) x (2 UNet-4ch + 1 UNet-8ch) + 2 decodes
-    (the 8-channel UNet differs only in conv_in: timed as the 4-channel one)."""
-    from oracle import fixtures
+# ------------------------------------------------------------------------------------------------
+# bare `python bench.py --gpus N`: start the ranks from a parent that never initialises the GPU
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, test infrastructure: only this leg imports it)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(res, steps, cores_hint=None, config1=True):
+    """Time the CPU oracle on a bounded sample of the bench workload: ONE SD-1.5 UNet evaluation (batch 1) and ONE VAE
+    decode at the bench resolution, float32, all host cores; extrapolate to one HDR image = (steps+1) x (2 UNet-4ch +
+    1 UNet-8ch) + 2 decodes (the 8-channel UNet differs only in conv_in: timed as the 4-channel one).  Beside it BASELINE.json
+    configs[0] (single 8-channel UNet, 1 prompt, 256x256, 10 PNDM steps, 2 decodes + Eq. 1) is timed IN FULL."""
+    import torch
+
+    from oracle import fixtures, pipelines as opipe, schedulers as osched
 
     cores = min(cores_hint or 16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     h = res // 8
+    out = {}
     with torch.no_grad():
-        unet = fixtures.build_unet("sd15", 4)
-        x = torch.randn(1, 4, h, h)
+        unet = fixtures.build_unet("sd15", 8)
+        x = torch.randn(1, 8, h, h)
         ctx = torch.randn(1, 77, 768)
         t0 = time.perf_counter()
         unet(x, torch.tensor(501), encoder_hidden_states=ctx)
         t_unet = time.perf_counter() - t0
-        del unet
         vae = fixtures.build_vae("sd15")
         t0 = time.perf_counter()
         vae.decode(torch.randn(1, 4, h, h))
         t_vae = time.perf_counter() - t0
+        if config1:
+            pos, neg, lat = fixtures.make_inputs(1, 32, 32)
+            sdr_lat = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(7)) * 0.7
+            t0 = time.perf_counter()
+            gm = opipe.gm_loop(unet, osched.PNDMScheduler(), sdr_lat, pos, neg, lat, num_inference_steps=10, guidance_scale=7.5)
+            opipe.decode_tail(vae, sdr_lat, gm, qmax=99)
+            t_c1 = time.perf_counter() - t0
+            out["config1_full"] = {"seconds": round(t_c1, 2), "value": round(1.0 / t_c1, 5), "unit": "HDR images/s",
+                                   "what": "BASELINE.json configs[0] timed in full: single 8-ch SD-1.5 UNet, 1 prompt, 256x256, 10 PNDM steps "
+                                           "(11 iterations at CFG batch 2), 2 VAE decodes + Eq. 1, float32"}
     per_image = (steps + 1) * 3 * t_unet + 2 * t_vae
-    return {
+    out.update({
         "value": 1.0 / per_image, "unit": "HDR images/s", "cores": cores, "kind": "port",
         "sample": f"CPU oracle (pure-torch fp32 restatement, NOT diffusers): 1 SD-1.5 UNet eval (batch 1, {h}x{h} latent) = "
                   f"{t_unet:.2f}s + 1 VAE decode {res}x{res} = {t_vae:.2f}s; extrapolated to {(steps + 1) * 3} UNet evals + 2 decodes per image",
-    }
+    })
+    return out
 
 
 def main():
     a = parse()
     if a.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(a.res, a.inference_steps)))
+        print(json.dumps(cpu_baseline(a.res, a.inference_steps, a.cpu_threads)))
         return
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))  # nothing above imported torch.cuda or made a HIP call
+
+    import hashlib
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,7 +159,7 @@ def main():
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
     dev = torch.device("cuda", local_rank)
     # GMD_BENCH_FORCE_DIST=1 runs the RCCL path (process group, broadcasts, barrier, max-reduce) with a single rank too:
-    # the only way to exercise it on a one-GPU box
+    # the only way to exercise it on a one-GPU box (tests/test_distributed_gpu.py)
     use_dist = world > 1 or (os.environ.get("GMD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -109,30 +168,42 @@ def main():
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     from gm_diffusion import distributed as gdist, hdr, profiling
-    from gm_diffusion.components import AutoencoderKL, DPMSolverMultistepScheduler, PNDMScheduler, UNet2DConditionModel
+    from gm_diffusion.components import AutoencoderKL, DDPMScheduler, DPMSolverMultistepScheduler, PNDMScheduler, UNet2DConditionModel
     from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     tiny = a.unet == "tiny"
     ucfg = dict(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, attention_head_dim=2, norm_num_groups=8) if tiny else {}
     vcfg = dict(block_out_channels=(64, 64, 128, 128), norm_num_groups=8) if tiny else {}
+
+    def make_sched():
+        kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1)
+        if a.scheduler == "dpm++":
+            return DPMSolverMultistepScheduler(timestep_spacing="leading", **kw)
+        if a.scheduler == "ddpm":
+            return DDPMScheduler(clip_sample=False, **kw)
+        return PNDMScheduler(num_train_timesteps=1000, skip_prk_steps=True, set_alpha_to_one=False, **kw)
+
+    def make_pipe(u, g, v):
+        p = StableDiffusionDualUNetPipeline(vae=v, text_encoder=None, tokenizer=None, unet=u, gm_unet=g, scheduler=make_sched(),
+                                            safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+        p.set_progress_bar_config(disable=True)
+        p.overlap_streams = not a.no_overlap
+        p.use_hip_graphs = not a.no_graphs
+        return p
+
     t_build = time.perf_counter()
     unet = UNet2DConditionModel(in_channels=4, **ucfg).init_random(1234).to(dev, dtype)
     gm_unet = UNet2DConditionModel(in_channels=8, **ucfg).init_random(1238).to(dev, dtype)
     vae = AutoencoderKL(**vcfg).init_random(1334).to(dev, dtype)
-    sched = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
-                          skip_prk_steps=True, steps_offset=1, set_alpha_to_one=False)
-    if a.scheduler == "dpm++":
-        sched = DPMSolverMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
-                                            timestep_spacing="leading")
-    pipe = StableDiffusionDualUNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, gm_unet=gm_unet,
-                                           scheduler=sched, safety_checker=None, feature_extractor=None,
-                                           requires_safety_checker=False)
-    pipe.set_progress_bar_config(disable=True)
-    pipe.overlap_streams = not a.no_overlap
-    pipe.use_hip_graphs = not a.no_graphs
+    pipe = make_pipe(unet, gm_unet, vae)
 
-    B = a.batch
+    if a.global_batch:
+        if a.global_batch % world:
+            raise SystemExit(f"--global-batch {a.global_batch} does not divide over {world} GPUs")
+        B = a.global_batch // world
+    else:
+        B = a.batch
     total = B * world
     cross = unet.config.cross_attention_dim
     h = a.res // 8
@@ -142,16 +213,21 @@ def main():
         pos = torch.randn(total, 77, cross, generator=ge)
         neg = torch.randn(total, 77, cross, generator=ge)
         lat = torch.randn(total, 4, h, h, generator=torch.Generator("cpu").manual_seed(42))
-    pos, neg, lat, _ = gdist.shard_prompt_batch(pos, neg, lat, total, (77, cross), (4, h, h), torch.float32, dev)
+    pos, neg, lat, _ = gdist.shard_prompt_batch(pos, neg, lat, total, (77, cross), (4, h, h), torch.float32, dev,
+                                                force=use_dist)
     pos, neg, lat = pos.to(dev), neg.to(dev), lat.to(dev)
     unet._ensure(); gm_unet._ensure(); vae._ensure()
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
+    gen_seed = 1234
 
-    def step():
-        sdr, gm = pipe(prompt_embeds=pos, negative_prompt_embeds=neg, latents=lat, height=a.res, width=a.res,
-                       num_inference_steps=a.inference_steps, guidance_scale=7.5, output_type="latent")
-        return hdr.decode_to_hdr(vae, sdr, gm, qmax=99.0, want=("sdr_u8", "gm_u8", "hdr", "hdr_u16"))
+    def step(p=pipe, v=vae, pe=pos, ne=neg, la=lat, n=a.inference_steps):
+        kw = {}
+        if a.scheduler == "ddpm":  # stochastic scheduler: one CPU generator shared by both scheduler steps (dual.py:1015)
+            kw["generator"] = torch.Generator("cpu").manual_seed(gen_seed)
+        sdr, gm = p(prompt_embeds=pe, negative_prompt_embeds=ne, latents=la, height=a.res, width=a.res,
+                    num_inference_steps=n, guidance_scale=7.5, output_type="latent", **kw)
+        return hdr.decode_to_hdr(v, sdr, gm, qmax=99.0, want=("sdr_u8", "gm_u8", "hdr", "hdr_u16")), sdr, gm
 
     def fence():
         torch.cuda.synchronize()
@@ -160,7 +236,7 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        out = step()
+        out, _, _ = step()
     fence()
     # Timed region: the product path as shipped (each UNet forward replayed from a captured HIP graph), no
     # instrumentation.  HIP events cannot bracket kernels inside a graph replay, so the per-kernel timing that feeds
@@ -168,7 +244,7 @@ def main():
     # parameters) right after the timed region, with torch.cuda.Event pairs on the launch stream around every launch.
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
+        out, _, _ = step()
     fence()
     elapsed = time.perf_counter() - t0
     timer = None
@@ -177,13 +253,7 @@ def main():
         timer = profiling.KernelTimer()
         profiling.set_timer(timer)  # an active timer makes the pipeline take the eager (non-graph) path
         pipe.overlap_streams = False  # one stream: an event pair then brackets exactly one kernel running alone
-        if a.event_lead_ms > 0:
-            # optional: park the stream behind a device-side delay so the host runs ahead of the GPU (measured: no effect on
-            # the per-kind averages -- the instrumented step is GPU-bound anyway)
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record(); torch.cuda._sleep(20_000_000); c1.record(); torch.cuda.synchronize()
-            torch.cuda._sleep(int(20_000_000 * a.event_lead_ms / max(c0.elapsed_time(c1), 1e-3)))
-        out_eager = step()
+        out_eager, _, _ = step()
         torch.cuda.synchronize()
         profiling.set_timer(None)
         # the shipped path (graph replay, two streams) and this eager single-stream step run the same kernels on the same
@@ -192,32 +262,74 @@ def main():
         pipe.overlap_streams = not a.no_overlap
     if use_dist:
         dist.barrier()
-    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(out["hdr"]).all().item())
+
+    # bf16 drift against the float32 HIP path on a SHORT fixed run (1 prompt, `--drift-steps` PNDM steps): the parity gate
+    # (latent RMS <= 1e-3 vs the oracle) is met by the float32 path; this is what the benchmarked precision gives up
+    drift = None
+    if rank == 0 and a.dtype == "bf16" and not a.no_drift and not tiny:
+        try:
+            f_unet = UNet2DConditionModel(in_channels=4, **ucfg).load_state_dict(unet.state_dict()).to(dev, torch.float32)
+            f_gm = UNet2DConditionModel(in_channels=8, **ucfg).load_state_dict(gm_unet.state_dict()).to(dev, torch.float32)
+            f_pipe = make_pipe(f_unet, f_gm, vae)
+            pe1, ne1, la1 = pos[:1].contiguous(), neg[:1].contiguous(), lat[:1].contiguous()
+            _, s_b, g_b = step(pipe, vae, pe1, ne1, la1, a.drift_steps)
+            _, s_f, g_f = step(f_pipe, vae, pe1, ne1, la1, a.drift_steps)
+            rms = lambda x, y: float(((x.double() - y.double()) ** 2).mean().sqrt().item())
+            drift = {"sdr": round(rms(s_b, s_f), 6), "gm": round(rms(g_b, g_f), 6), "latent_rms": round(float(s_f.double().pow(2).mean().sqrt().item()), 4),
+                     "pndm_steps": a.drift_steps, "prompts": 1, "resolution": a.res,
+                     "note": "RMS difference of the final latents, bf16 path vs the float32 HIP path (same weights, seed, embeddings); "
+                             "north-star gate 1e-3 is met by the float32 path against the oracle (tests/test_pipeline_gpu.py)"}
+            del f_pipe, f_unet, f_gm
+            torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            drift = {"error": repr(e)}
 
     if rank == 0:
         roof = None
         kernels = {}
         if timer is not None:
             full = timer.summary()
-            kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_us": round(v["avg_us"], 2),
-                           "tflops": round(v["tflops"], 2)} for k, v in full.items()}
-            dom = full["conv3x3"]
-            roof = {"kernel": "gmd_conv3x3 (gemm_ring_kernel<CONV=true>: implicit-GEMM conv3x3, 49.6% of UNet / 96.8% of VAE FLOPs)",
-                    "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": BF16_DENSE_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(dom["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
-                    "traffic_note": "PMC needs its own rocprofv3 passes: profiles/r01_pmc_conv_hbm_traffic.txt (fabric reads 1.6x algorithmic)",
+            mfma_peak = BF16_DENSE_PEAK_TFLOPS if a.dtype == "bf16" else F32_VECTOR_PEAK_TFLOPS
+            all_ms = sum(v["ms"] for v in full.values())
+            for k, v in full.items():
+                e = {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_us": round(v["avg_us"], 2), "share": round(v["ms"] / all_ms, 3)}
+                if k in MFMA_KINDS:
+                    e.update(bound="mfma", tflops=round(v["tflops"], 2), frac=round(v["tflops"] / mfma_peak, 4))
+                else:
+                    e.update(bound="hbm", gbps=round(v["gbps"], 1), frac=round(v["gbps"] / HBM_PEAK_GBPS, 4))
+                kernels[k] = e
+            dk = max(full, key=lambda k: full[k]["ms"])  # the kind with the largest measured time
+            dom = full[dk]
+            traffic, traffic_note = None, "no PMC record for this kind under profiles/"
+            try:
+                with open(PMC_TRAFFIC_FILE) as f:
+                    rec = json.load(f).get(dk)
+                if rec:
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_note = rec["note"]
+            except (OSError, ValueError, KeyError):
+                pass
+            mf = dk in MFMA_KINDS
+            roof = {"kernel": KIND_KERNEL.get(dk, dk), "kind": dk, "bound": "mfma" if mf else "hbm",
+                    "achieved": round(dom["tflops"] if mf else dom["gbps"], 2), "peak": mfma_peak if mf else HBM_PEAK_GBPS,
+                    "unit": "TFLOP/s" if mf else "GB/s",
+                    "frac": round((dom["tflops"] / mfma_peak) if mf else (dom["gbps"] / HBM_PEAK_GBPS), 4),
+                    "traffic": traffic, "traffic_note": traffic_note,
                     "launches": dom["launches"], "avg_launch_us": round(dom["avg_us"], 2),
-                    "flops_per_launch_avg": round(dom["flops"] / dom["launches"]),
-                    "measured": "HIP events around every conv3x3 launch of one extra eager, single-stream step after the timed "
-                                "region (the timed region replays HIP graphs on two streams, which events cannot enter)",
-                    "share_of_instrumented_kernel_time": round(dom["ms"] / sum(v["ms"] for v in full.values()), 3)}
+                    ("flops_per_launch_avg" if mf else "bytes_per_launch_avg"): round((dom["flops"] if mf else dom["bytes"]) / dom["launches"]),
+                    "measured": "HIP events around every launch of this kind in one extra eager, single-stream step after the timed "
+                                "region (the timed region replays HIP graphs on two streams, which events cannot enter); chosen as the "
+                                "kind with the largest measured time over ALL instrumented kinds",
+                    "share_of_instrumented_kernel_time": round(dom["ms"] / all_ms, 3)}
+        is_metric = a.scheduler == "pndm" and a.inference_steps == 50 and a.res == 512 and a.dtype == "bf16"
         res = {
-            "metric": ("HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet" if a.scheduler == "pndm" and a.inference_steps == 50 and a.res == 512
-                       else f"HDR images/sec @ {a.res}x{a.res}, {a.inference_steps} {a.scheduler} steps, dual-UNet [not the BASELINE metric]"), "value": round(total * a.steps / elapsed, 4),
+            "metric": ("HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet" if is_metric
+                       else f"HDR images/sec @ {a.res}x{a.res}, {a.inference_steps} {a.scheduler} steps, dual-UNet, {a.dtype} [not the BASELINE metric]"),
+            "value": round(total * a.steps / elapsed, 4),
             "unit": "HDR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
@@ -225,15 +337,20 @@ def main():
                                    f"({a.inference_steps + (1 if a.scheduler == 'pndm' else 0)} iterations), CFG 7.5, batch {B}/GPU, 2 VAE decodes + Eq.1 HDR tail"
                                    + (" [TINY smoke config - not a valid bench]" if tiny else ""),
                        "global_batch": total, "per_gpu_batch": B, "resolution": a.res, "inference_steps": a.inference_steps,
-                       "parallelism": f"prompt-batch sharding x{world}, RCCL broadcast of text hidden states + latents"},
-            "outputs_finite": finite, "graph_vs_eager_max_abs_diff": path_diff, "setup_s": round(t_build, 1), "kernels": kernels, "roofline": roof,
+                       "parallelism": f"prompt-batch sharding x{world}, RCCL broadcast of text hidden states + latents",
+                       "rccl_world_size": dist.get_world_size() if use_dist else None},
+            "outputs_finite": finite, "graph_vs_eager_max_abs_diff": path_diff, "setup_s": round(t_build, 1),
+            "latent_rms_vs_f32": drift, "kernels": kernels, "roofline": roof,
         }
+        if a.checksum:
+            res["output_sha256"] = hashlib.sha256(out["hdr_u16"].cpu().numpy().tobytes()).hexdigest()
         if not a.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.res, a.inference_steps, a.cpu_threads)
             except Exception as e:  # pragma: no cover
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
+        sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,6 +17,7 @@
 // gathered on the fly (zero padding, stride 2, fused nearest-2x upsample) -- no im2col buffer.
 #include "gmd_common.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -992,6 +993,14 @@ struct Plan {
     int bm, bn, pf, ksplit;
 };
 
+struct Force {
+    int bm = 0, bn = 0, pf = 0, ks = 0;
+    Force() {
+        if (const char* f = getenv("GMD_GEMM_FORCE")) sscanf(f, "%d,%d,%d,%d", &bm, &bn, &pf, &ks);
+    }
+};
+Force g_force;  // read once when the library is loaded
+
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
 // deep K (the 8x8 / 16x16 UNet levels: K up to 23040) are split along K.
@@ -1001,9 +1010,10 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
         pl.bm = 128;
         pl.bn = (N % 160 == 0 && !pair_tiles) ? 160 : 128;  // GEGLU needs an even number of 16-column tiles per wave
     }
-    const char* f = getenv("GMD_GEMM_FORCE");  // "bm,bn,pf,ksplit" (0 = keep heuristic) -- tuning experiments only
-    int fbm = 0, fbn = 0, fpf = 0, fks = 0;
-    if (f) sscanf(f, "%d,%d,%d,%d", &fbm, &fbn, &fpf, &fks);
+    // GMD_GEMM_FORCE="bm,bn,pf,ksplit" (0 = keep heuristic): tuning experiments only (tools/bench_gemm.py).  Parsed ONCE per
+    // process
+    // -- the launch path itself never touches the environment; gmd_gemm_plan_override() changes it in-process for A/B runs.
+    const int fbm = g_force.bm, fbn = g_force.bn, fpf = g_force.pf, fks = g_force.ks;
     if (fbm && fbn) { pl.bm = fbm; pl.bn = fbn; }
     if (fpf) pl.pf = fpf == 9 ? 0 : fpf;  // 9 selects the LDS-DMA pipeline (pf 0)
     int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
@@ -1030,15 +1040,34 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
     return pl;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-(function, device) property: remember it per device, so a
+// process that drives several GPUs (not the one-process-per-GPU design, but legal) opts in on each of them.
+hipError_t opt_in_lds(const void* fn, int bytes) {
+    constexpr int kMaxDev = 64, kMaxFn = 64;
+    static const void* fns[kMaxFn];
+    static unsigned long long done[kMaxFn];  // bit d: set on device d
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    int slot = -1;
+    for (int i = 0; i < kMaxFn; ++i) {
+        if (fns[i] == fn) { slot = i; break; }
+        if (fns[i] == nullptr) { fns[i] = fn; slot = i; break; }
+    }
+    if (slot >= 0 && dev < kMaxDev && (done[slot] >> dev & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && slot >= 0 && dev < kMaxDev) done[slot] |= 1ull << dev;
+    return e;
+}
+
 template <bool CONV, int BM, int BN, int PF>
 hipError_t launch_bf16(const GemmParams& p, int gz, hipStream_t s) {
     constexpr size_t smem = 2 * (BM + BN) * 128;
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
-    if (smem > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, BM, BN, PF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into once per (kernel, device)
+        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, BM, BN, PF>), (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, gz);
     gemm_bf16_kernel<CONV, BM, BN, PF><<<grid, 256, smem, s>>>(p);
@@ -1049,12 +1078,9 @@ template <bool CONV, int WM, int WN, int TN, int NST>
 hipError_t launch_ring(const GemmParams& p, int gz, hipStream_t s) {
     constexpr int BM = WM * 64, BN = WN * TN * 16;
     constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (smem > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<CONV, WM, WN, TN, NST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 64 * 1024) {
+        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_ring_kernel<CONV, WM, WN, TN, NST>), (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);  // 1-D tile index, remapped per XCD in the kernel
     gemm_ring_kernel<CONV, WM, WN, TN, NST><<<grid, WM * WN * 64, smem, s>>>(p);
@@ -1112,6 +1138,12 @@ int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipSt
 }  // namespace
 
 extern "C" {
+
+int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit) {
+    GMD_REQUIRE(bm >= 0 && bn >= 0 && pf >= 0 && ksplit >= 0, "gmd_gemm_plan_override: negative value");
+    g_force.bm = bm; g_force.bn = bn; g_force.pf = pf; g_force.ks = ksplit;
+    return GMD_OK;
+}
 
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype, int M, int N, int K, int64_t lda,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,

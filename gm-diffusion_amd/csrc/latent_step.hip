@@ -79,6 +79,41 @@ __global__ __launch_bounds__(kThreads) void dpm_step_kernel(
     }
 }
 
+// DDPM ancestral step (the scheduler scripts/inference/generate_hdr.py:162 constructs) fused with the CFG combine and the
+// pipeline's x0, in the operation order of the torch expressions of diffusers' DDPMScheduler.step (float32, no FMA):
+//   x0    = (x - sqrt(1-a_t) * eps) / sqrt(a_t)            [clamped to +-clip_range when clip_sample]
+//   prev  = x0_coeff * x0 + xt_coeff * x                    posterior mean, formula (7) of the DDPM paper
+//   prev  = prev + noise_scale * noise                      t > 0 only (noise == nullptr at the last step)
+// The noise tensor is drawn by the HOST scheduler with randn_tensor(generator) so that the shared generator of the dual
+// pipeline is consumed in the reference's order (SDR step first, GM step second: stable_diffusion_dual_unet.py:1077, 1093).
+__global__ __launch_bounds__(kThreads) void ddpm_step_kernel(
+    const float* __restrict__ eps_in, const float* __restrict__ x, const float* __restrict__ noise, int B, int64_t chw, int do_cfg,
+    float gs, const float* __restrict__ ratio, float gr, float sched_sqrt_a, float sched_sqrt_1ma, int clip, float clip_range,
+    float x0_coeff, float xt_coeff, float noise_scale, float sqrt_a, float sqrt_1ma, float* __restrict__ x_prev,
+    float* __restrict__ x0) {
+    const int64_t n = (int64_t)B * chw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float eps;
+        if (do_cfg) {
+            const float u = eps_in[i], t = eps_in[n + i];
+            eps = u + gs * (t - u);  // dual.py:1065
+            if (ratio) {             // rescale_noise_cfg, dual.py:91-93
+                const float resc = eps * ratio[i / chw];
+                eps = gr * resc + (1.0f - gr) * eps;
+            }
+        } else {
+            eps = eps_in[i];
+        }
+        const float xt = x[i];
+        if (x0) x0[i] = (xt - sqrt_1ma * eps) / sqrt_a;  // dual.py:1075 (never clipped)
+        float p0 = (xt - sched_sqrt_1ma * eps) / sched_sqrt_a;
+        if (clip) p0 = fminf(fmaxf(p0, -clip_range), clip_range);
+        float r = x0_coeff * p0 + xt_coeff * xt;
+        if (noise) r = r + noise_scale * noise[i];
+        x_prev[i] = r;
+    }
+}
+
 // one block per sample: unbiased std over chw of text eps and of the guided eps
 __global__ __launch_bounds__(kThreads) void cfg_std_ratio_kernel(const float* __restrict__ eps_in, int B, int64_t chw,
                                                                  float gs, float* __restrict__ ratio) {
@@ -193,6 +228,22 @@ int gmd_dpm_step(const float* eps_in, const float* x, const float* m1, int B, in
         eps_in, x, m1, B, chw, do_cfg, guidance_scale, do_cfg ? rescale_ratio : nullptr, guidance_rescale, order, sigma_s0, alpha_s0,
         c_x, c_m, c_h, inv_r0, sqrt_alpha, sqrt_one_minus_alpha, m0_out, x_prev, x0);
     GMD_CHECK_LAUNCH("gmd_dpm_step");
+    return GMD_OK;
+}
+
+int gmd_ddpm_step(const float* eps_in, const float* x, const float* noise, int B, int64_t chw, int do_cfg, float guidance_scale,
+                  const float* rescale_ratio, float guidance_rescale, float sched_sqrt_alpha, float sched_sqrt_one_minus_alpha,
+                  int clip_sample, float clip_range, float x0_coeff, float xt_coeff, float noise_scale, float sqrt_alpha,
+                  float sqrt_one_minus_alpha, float* x_prev, float* x0, gmd_stream_t stream) {
+    GMD_REQUIRE(B >= 0 && chw > 0, "gmd_ddpm_step: bad shape B=%d chw=%lld", B, (long long)chw);
+    if (B == 0) return GMD_OK;
+    GMD_REQUIRE(eps_in && x && x_prev, "gmd_ddpm_step: null pointer");
+    GMD_REQUIRE(sched_sqrt_alpha != 0.0f && (x0 == nullptr || sqrt_alpha != 0.0f), "gmd_ddpm_step: zero denominator");
+    GMD_REQUIRE(!clip_sample || clip_range > 0.0f, "gmd_ddpm_step: clip_range must be positive");
+    ddpm_step_kernel<<<grid_for((int64_t)B * chw), kThreads, 0, (hipStream_t)stream>>>(
+        eps_in, x, noise, B, chw, do_cfg, guidance_scale, do_cfg ? rescale_ratio : nullptr, guidance_rescale, sched_sqrt_alpha,
+        sched_sqrt_one_minus_alpha, clip_sample, clip_range, x0_coeff, xt_coeff, noise_scale, sqrt_alpha, sqrt_one_minus_alpha, x_prev, x0);
+    GMD_CHECK_LAUNCH("gmd_ddpm_step");
     return GMD_OK;
 }
 

@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 GMD_F32, GMD_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -35,9 +35,11 @@ SIGNATURES = {
     "gmd_rgbe_encode": [P, P, L, P],
     "gmd_latent_step": [P, P, P, P, P, P, I, L, I, F, P, F, I, F, F, F, F, F, P, P, P, P],
     "gmd_dpm_step": [P, P, P, I, L, I, F, P, F, I, F, F, F, F, F, F, F, F, P, P, P, P],
+    "gmd_ddpm_step": [P, P, P, I, L, I, F, P, F, F, F, I, F, F, F, F, F, F, P, P, P],
     "gmd_cfg_std_ratio": [P, I, L, F, P, P],
     "gmd_pack_unet_input": [P, I, P, I, I, L, I, P, I, I, P],
     "gmd_unpack_nchw": [P, I, L, I, I, L, P, P],
+    "gmd_gemm_plan_override": [I, I, I, I],
     "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, L, P],
     "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, L, P, P, L, P],
     "gmd_attention": [P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],

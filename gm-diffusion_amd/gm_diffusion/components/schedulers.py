@@ -271,7 +271,45 @@ class DDPMScheduler(_SchedulerBase):
             variance = cur_b
         return variance
 
+    def _device_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0, generator):
+        """One HIP kernel pass (gmd_ddpm_step): CFG combine (+rescale), pipeline x0, clipped x0 prediction, posterior mean
+        and the variance noise.  The noise is drawn HERE with ``randn_tensor`` exactly where ``step`` draws it, so the
+        generator the dual pipeline shares between its two schedulers (stable_diffusion_dual_unet.py:1015, 1077, 1093) is
+        consumed in the reference's order."""
+        t = int(timestep)
+        prev_t = int(self.previous_timestep(t))
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        b_t, b_p = 1 - a_t, 1 - a_p
+        cur_a = a_t / a_p
+        cur_b = 1 - cur_a
+        x0_coeff = (a_p ** 0.5 * cur_b) / b_t
+        xt_coeff = cur_a ** 0.5 * b_p / b_t
+        noise, scale = None, 0.0
+        if t > 0:
+            noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=torch.float32)
+            v = self._get_variance(t)
+            scale = (v if self.config.variance_type == "fixed_small_log" else v ** 0.5).item()
+        ratio = ops.cfg_std_ratio(eps_in, guidance_scale) if (do_cfg and guidance_rescale > 0.0) else None
+        return ops.ddpm_step(eps_in.contiguous(), sample.contiguous(),
+                             ((a_t ** 0.5).item(), (b_t ** 0.5).item(), x0_coeff.item(), xt_coeff.item(), scale,
+                              a_t.sqrt().item(), (1 - a_t).sqrt().item()),
+                             do_cfg, guidance_scale, noise=noise, ratio=ratio, guidance_rescale=guidance_rescale,
+                             clip_range=self.config.clip_sample_range if self.config.clip_sample else None, want_x0=want_x0)
+
+    def fused_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale=0.0, want_x0=False, generator=None):
+        """Same contract as ``PNDMScheduler.fused_step`` plus the generator (device float32 tensors only).
+        Returns (prev_sample, x0 | None)."""
+        return self._device_step(eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0, generator)
+
     def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        if model_output.is_cuda and model_output.dtype == torch.float32 and sample.dtype == torch.float32:
+            prev, _ = self._device_step(model_output, timestep, sample, False, 1.0, 0.0, False, generator)
+            return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)
+        return self._host_step(model_output, timestep, sample, generator, return_dict)
+
+    def _host_step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        """The torch expressions of diffusers' ``DDPMScheduler.step`` (host tensors; also the reference for the kernel test)."""
         t = int(timestep)
         prev_t = int(self.previous_timestep(t))
         a_t = self.alphas_cumprod[t]
@@ -431,8 +469,9 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
         self._advance(m0)
         return prev, x0
 
-    def fused_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale=0.0, want_x0=False):
-        """Same contract as ``PNDMScheduler.fused_step`` (device tensors only).  Returns (prev_sample, x0 | None)."""
+    def fused_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale=0.0, want_x0=False, generator=None):
+        """Same contract as ``PNDMScheduler.fused_step`` (device tensors only; ``generator`` is accepted because ``step`` has
+        the parameter, and unused: this solver is deterministic).  Returns (prev_sample, x0 | None)."""
         return self._device_step(eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0)
 
     def step(self, model_output, timestep, sample, generator=None, variance_noise=None, return_dict=True):

@@ -32,9 +32,15 @@ def shard_range(total, rank=None, world=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_from_rank0(t, shape, dtype, device, group=None):
+def _active(force=False):
+    """Collectives run when there is more than one rank -- or, with ``force``, whenever a process group exists (a
+    single-rank RCCL group: the one way to drive the collective path on a one-GPU box)."""
+    return is_dist() or (force and dist.is_available() and dist.is_initialized())
+
+
+def broadcast_from_rank0(t, shape, dtype, device, group=None, force=False):
     """Rank 0 passes the tensor, other ranks pass None and receive a tensor of the agreed shape."""
-    if not is_dist():
+    if not _active(force):
         return t
     if dist.get_rank() != 0:
         t = torch.empty(shape, dtype=dtype, device=device)
@@ -45,19 +51,19 @@ def broadcast_from_rank0(t, shape, dtype, device, group=None):
 
 
 def shard_prompt_batch(prompt_embeds, negative_prompt_embeds, latents, total_batch, embed_shape, latent_shape,
-                       dtype=torch.float32, device="cpu", group=None):
+                       dtype=torch.float32, device="cpu", group=None, force=False):
     """Broadcast the full-batch conditioning from rank 0 and return this rank's slice
     ``(prompt_embeds, negative_prompt_embeds, latents, (lo, hi))``.
 
     On rank 0 the three tensors are the full batch; on other ranks they are ignored (may be None)."""
-    if not is_dist():
+    if not _active(force):
         return prompt_embeds, negative_prompt_embeds, latents, (0, total_batch)
     full_e = (total_batch,) + tuple(embed_shape)
     full_l = (total_batch,) + tuple(latent_shape)
     r0 = dist.get_rank() == 0
     both = torch.cat([negative_prompt_embeds, prompt_embeds]) if r0 else None  # one payload, [2B, L, E]
-    both = broadcast_from_rank0(both, (2 * total_batch,) + tuple(embed_shape), dtype, device, group)
-    latents = broadcast_from_rank0(latents if r0 else None, full_l, torch.float32, device, group)
+    both = broadcast_from_rank0(both, (2 * total_batch,) + tuple(embed_shape), dtype, device, group, force)
+    latents = broadcast_from_rank0(latents if r0 else None, full_l, torch.float32, device, group, force)
     lo, hi = shard_range(total_batch)
     neg, pos = both[:total_batch], both[total_batch:]
     return pos[lo:hi].contiguous(), neg[lo:hi].contiguous(), latents[lo:hi].contiguous(), (lo, hi)

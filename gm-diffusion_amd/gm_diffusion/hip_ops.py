@@ -18,7 +18,7 @@ from . import profiling
 from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
+    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
     "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "groupnorm_split", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
@@ -113,6 +113,14 @@ def _f32(t, name):
     if t is not None and t.dtype != torch.float32:
         raise HipExtensionError(f"{name} must be float32")
     return t
+
+
+def _timed(kind):
+    """(timer, start event) when a KernelTimer is active and wants ``kind``, else (None, None)."""
+    tm = profiling.active()
+    if tm is None or not tm.wants(kind):
+        return None, None
+    return tm, tm.begin()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -272,16 +280,25 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
     epw = 2 if x.dtype == torch.bfloat16 else 1
     cpg = C // groups
     vec16 = (cpg * x.element_size()) % 16 == 0 and (C * x.element_size()) % 16 == 0
+    # algorithmic HBM bytes of a GroupNorm: the activation is read once and written once (the statistics pass of the split
+    # path re-reads it: that second read is what the roofline fraction of this kind exposes)
+    nbytes = 2 * x.numel() * x.element_size()
     if cpg % epw == 0 and HW * cpg * x.element_size() <= (GN_FUSED_MAX_SLAB_VEC16 if vec16 else GN_FUSED_MAX_SLAB):
         y = torch.empty_like(x)
+        tm, t0 = _timed("groupnorm")
         check(lib().gmd_groupnorm_fused(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
                                         _ptr(_f32(beta, "beta")), int(silu), _stream()), "gmd_groupnorm_fused")
+        if tm:
+            tm.end("groupnorm", 0.0, nbytes, t0)
         return y
     nsplit = lib().gmd_groupnorm_nsplit(HW)
     ws = torch.empty(B * nsplit * groups * 2, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
+    tm, t0 = _timed("groupnorm")
     check(lib().gmd_groupnorm_split(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
                                     _ptr(_f32(beta, "beta")), _ptr(ws), int(silu), _stream()), "gmd_groupnorm_split")
+    if tm:
+        tm.end("groupnorm", 0.0, nbytes, t0)
     return y
 
 
@@ -293,8 +310,11 @@ def layernorm(x, gamma, beta, eps=1e-5):
     _dev(x, gamma, beta)
     C = x.shape[-1]
     y = torch.empty_like(x)
+    tm, t0 = _timed("layernorm")
     check(lib().gmd_layernorm(_ptr(x), _ptr(y), dtype_code(x.dtype), x.numel() // C, C, _ptr(_f32(gamma, "gamma")),
                               _ptr(_f32(beta, "beta")), float(eps), _stream()), "gmd_layernorm")
+    if tm:
+        tm.end("layernorm", 0.0, 2 * x.numel() * x.element_size(), t0)
     return y
 
 
@@ -323,8 +343,11 @@ def concat_channels(a, b):
     if b.numel() // cb != rows or a.dtype != b.dtype:
         raise HipExtensionError("concat_channels: row count / dtype mismatch")
     out = torch.empty(a.shape[:-1] + (ca + cb,), dtype=a.dtype, device=a.device)
+    tm, t0 = _timed("concat")
     check(lib().gmd_concat_channels(_ptr(a), ca, _ptr(b), cb, _ptr(out), dtype_code(a.dtype), rows, _stream()),
           "gmd_concat_channels")
+    if tm:
+        tm.end("concat", 0.0, 2 * out.numel() * out.element_size(), t0)
     return out
 
 
@@ -423,6 +446,27 @@ def dpm_step(eps_in, x, order, coefs, do_cfg, guidance_scale, m1=None, ratio=Non
     return m0, x_prev, x0
 
 
+def ddpm_step(eps_in, x, coefs, do_cfg, guidance_scale, noise=None, ratio=None, guidance_rescale=0.0, clip_range=None,
+              want_x0=False):
+    """Fused CFG + x0 + DDPM ancestral update.  coefs = (sched_sqrt_alpha, sched_sqrt_one_minus_alpha, x0_coeff, xt_coeff,
+    noise_scale, sqrt_alpha, sqrt_one_minus_alpha); ``noise`` is None at the last step (t == 0); ``clip_range`` None = no
+    clip_sample.  Returns (x_prev, x0|None)."""
+    _dev(eps_in, x, noise, ratio)
+    for t in (eps_in, x, noise):
+        _f32(t, "latent tensors")
+    if noise is not None and noise.shape != x.shape:
+        raise HipExtensionError("ddpm_step: noise must have the sample's shape")
+    B = x.shape[0]
+    chw = x.shape[1:].numel()
+    x_prev = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    sa, s1, c0, ct, ns, pa, p1 = (float(v) for v in coefs)
+    check(lib().gmd_ddpm_step(_ptr(eps_in), _ptr(x), _ptr(noise), B, chw, int(do_cfg), float(guidance_scale), _ptr(ratio),
+                              float(guidance_rescale), sa, s1, int(clip_range is not None), float(clip_range or 0.0), c0, ct, ns, pa, p1,
+                              _ptr(x_prev), _ptr(x0), _stream()), "gmd_ddpm_step")
+    return x_prev, x0
+
+
 # ----------------------------------------------------------------------------------------------
 # HDR tail
 # ----------------------------------------------------------------------------------------------
@@ -438,9 +482,13 @@ def hdr_tail(sdr_dec, gm_dec, layout, B, H, W, qmax=99.0, eps=1 / 64, clamp=Fals
              "hdr": torch.float32, "hdr_file": torch.float32, "hdr_u16": torch.uint16}
     out = {k: torch.empty(shp, dtype=kinds[k], device=dev) for k in want}
     g = lambda k: _ptr(out.get(k))
+    tm, t0 = _timed("hdr_tail")
     check(lib().gmd_hdr_tail(_ptr(sdr_dec), _ptr(gm_dec), dtype_code(sdr_dec.dtype), layout, B, H, W, float(qmax), float(eps),
                              1 if clamp else 0, g("sdr"), g("gm"), g("sdr_u8"), g("gm_u8"), g("hdr"), g("hdr_file"),
                              g("hdr_u16"), _stream()), "gmd_hdr_tail")
+    if tm:  # 2 x 3 float32 read per pixel + every requested output written once
+        px = B * H * W
+        tm.end("hdr_tail", 0.0, px * 2 * 3 * sdr_dec.element_size() + sum(v.numel() * v.element_size() for v in out.values()), t0)
     return out
 
 

@@ -155,14 +155,16 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                     sdr_noise_pred = g_sdr.replay() if g_sdr else self.unet.forward_packed(x, x.shape[0], h, w, ctx)
                     pre_step = latents
                     latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, ts_host[i], pre_step, do_cfg, self.guidance_scale,
-                                                                   self.guidance_rescale if do_cfg else 0.0, want_x0=True)
+                                                                   self.guidance_rescale if do_cfg else 0.0, want_x0=True,
+                                                                   **self._fused_step_kwargs(extra_step_kwargs))
                     with torch.cuda.stream(gm_stream):
                         gm_stream.wait_stream(sdr_stream)  # x0_i is ready
                         x0_latent.record_stream(gm_stream)
                         gx = self.gm_unet.pack_input((x0_latent, gm_latents), dup=1, out=g_gm.x if g_gm else None)
                         self.gm_unet.set_timestep_from(ts_dev, i)
                         gm_noise_pred = g_gm.replay() if g_gm else self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
-                        gm_latents = self.gm_scheduler.step(gm_noise_pred, ts_host[i], gm_latents, return_dict=False)[0]
+                        gm_latents = self.gm_scheduler.step(gm_noise_pred, ts_host[i], gm_latents,
+                                                            **self._fused_step_kwargs(extra_step_kwargs), return_dict=False)[0]
                 else:
                     latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
                     latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)

@@ -308,10 +308,16 @@ class _GMPipelineBase(DiffusionPipeline):
     def _use_fused(self, latents, unet, scheduler):
         from ..components.unet_2d_condition import UNet2DConditionModel
 
-        from ..components.schedulers import DPMSolverMultistepScheduler
+        from ..components.schedulers import DDPMScheduler, DPMSolverMultistepScheduler
 
-        return (latents.is_cuda and isinstance(scheduler, (PNDMScheduler, DPMSolverMultistepScheduler))
+        return (latents.is_cuda and isinstance(scheduler, (PNDMScheduler, DPMSolverMultistepScheduler, DDPMScheduler))
                 and isinstance(unet, UNet2DConditionModel))
+
+    @staticmethod
+    def _fused_step_kwargs(extra_step_kwargs):
+        """What ``scheduler.fused_step`` takes of the reference's ``extra_step_kwargs``: the generator (stochastic
+        schedulers draw their noise from it in call order, stable_diffusion_dual_unet.py:1077, 1093)."""
+        return {"generator": extra_step_kwargs["generator"]} if "generator" in extra_step_kwargs else {}
 
     def _default_hw(self, height, width):
         if not height or not width:
@@ -424,7 +430,8 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
                     self.unet.set_timestep_from(ts_dev, i)
                     noise_pred = graph.replay() if graph else self.unet.forward_packed(x, x.shape[0], hw[0], hw[1], ctx)
                     latents, _ = self.scheduler.fused_step(noise_pred, ts_host[i], latents, do_cfg, self.guidance_scale,
-                                                           self.guidance_rescale if do_cfg else 0.0)
+                                                           self.guidance_rescale if do_cfg else 0.0,
+                                                           **self._fused_step_kwargs(extra_step_kwargs))
                 else:
                     cat_latents = torch.cat([sdr_latent, latents], dim=1)
                     latent_model_input = torch.cat([cat_latents] * 2) if do_cfg else cat_latents

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 3
+#define GMD_ABI_VERSION 4
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -130,6 +130,19 @@ int gmd_dpm_step(const float* eps_in, const float* x, const float* m1, int B, in
                  float sqrt_alpha, float sqrt_one_minus_alpha,
                  float* m0_out, float* x_prev, float* x0, gmd_stream_t stream);
 
+/* DDPM ancestral step -- the scheduler the reference's Stage-3 CLI constructs (scripts/inference/generate_hdr.py:162,
+ * used by the pipeline call at :212-218) -- fused with the same CFG combine / rescale and pipeline x0 as gmd_latent_step,
+ * in the float32 operation order of diffusers' DDPMScheduler.step:
+ *   p0 = (x - sched_sqrt_one_minus_alpha*eps)/sched_sqrt_alpha [clamp +-clip_range];  x_prev = x0_coeff*p0 + xt_coeff*x
+ *   [ + noise_scale*noise when noise != NULL (t > 0) ].
+ * `noise` is drawn by the host scheduler from the caller's generator, so a generator shared by the two schedulers of the
+ * dual pipeline is consumed SDR first, GM second (stable_diffusion_dual_unet.py:1015, 1077, 1093). */
+int gmd_ddpm_step(const float* eps_in, const float* x, const float* noise, int B, int64_t chw,
+                  int do_cfg, float guidance_scale, const float* rescale_ratio, float guidance_rescale,
+                  float sched_sqrt_alpha, float sched_sqrt_one_minus_alpha, int clip_sample, float clip_range,
+                  float x0_coeff, float xt_coeff, float noise_scale, float sqrt_alpha, float sqrt_one_minus_alpha,
+                  float* x_prev, float* x0, gmd_stream_t stream);
+
 /* per-sample unbiased std of the text eps and of the guided eps -> ratio[b] = std_text/std_cfg
  * (rescale_noise_cfg, stable_diffusion_dual_unet.py:88-91) */
 int gmd_cfg_std_ratio(const float* eps_in, int B, int64_t chw, float guidance_scale,
@@ -150,6 +163,12 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
  * `diffusers` dependency: UNet2DConditionModel / AutoencoderKL called at
  * stable_diffusion_gm.py:1051,1094 and stable_diffusion_dual_unet.py:1052,1083)
  * ---------------------------------------------------------------------------------- */
+
+/* Tuning hook (tools/bench_gemm.py, tools/check_ring.py; never called by the product path): pin the tile (bm x bn), the
+ * operand pipeline (pf: 9 = LDS-DMA, 1/2 = register staged, 1xx = ring variants) and the split-K factor of every later
+ * gmd_gemm_nt / gmd_conv3x3 launch of this process; 0 keeps the heuristic for that field, (0,0,0,0) restores it.  The
+ * environment variable GMD_GEMM_FORCE="bm,bn,pf,ksplit" seeds the same override once, when the library is loaded. */
+int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit);
 
 /* C[b] = act(alpha * A[b] @ W[b]^T + bias + rowbias + residual).
  * A: [M,K] ld lda; W: [N,K] ld ldw (both K-contiguous); C: [M,N] ld ldc, out_dtype F32 or `dtype`.

@@ -1,0 +1,35 @@
+"""GPU: the RCCL leg of bench.py on a one-GPU box -- a single-rank process group (GMD_BENCH_FORCE_DIST=1) drives
+init_process_group("nccl"), both broadcasts, the barrier and the max-reduce; the sharded run must give bit-identical
+HDR codes to the plain run (sharding must not change per-sample results)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--unet", "tiny", "--res", "128", "--batch", "2", "--inference-steps", "4", "--steps", "1", "--warmup", "0",
+        "--no-cpu-baseline", "--no-kernel-timing", "--no-drift", "--checksum"]
+
+
+def _run(env_extra):
+    env = dict(os.environ, **env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_single_rank_rccl_run_equals_plain_run():
+    plain = _run({})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    sharded = _run({"GMD_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port)})
+    assert plain["config"]["rccl_world_size"] is None and sharded["config"]["rccl_world_size"] == 1
+    assert plain["outputs_finite"] and sharded["outputs_finite"]
+    assert plain["output_sha256"] == sharded["output_sha256"]

@@ -95,7 +95,7 @@ def test_unet_1024_batch_independence(sd15):
         assert rel(both[i:i + 1].float(), one.float()) < 3e-2
 
 
-@pytest.mark.parametrize("res,batch,steps", [(512, 4, 4), (1024, 1, 3)])
+@pytest.mark.parametrize("res,batch,steps", [(512, 4, 4), (1024, 1, 3), (1024, 8, 2)])  # last: BASELINE configs[3] as stated (batch 8)
 def test_pipeline_fullsize_graph_equals_eager_and_tail(sd15, res, batch, steps):
     from gm_diffusion import hdr
 

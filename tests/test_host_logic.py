@@ -419,3 +419,37 @@ def test_pipeline_from_pretrained_directory(tmp_path):
     # single-UNet pipeline from the same directory with the 8-channel UNet passed in (generate_hdr.py:169-176)
     gp = StableDiffusionGMPipeline.from_pretrained(str(root), unet=gm, tokenizer=None, safety_checker=None, requires_safety_checker=False)
     assert gp.unet is gm and isinstance(gp.vae, AutoencoderKL)
+
+
+def test_bench_self_spawns_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus 2` with no RANK in the environment: the parent must start 2 ranks through
+    torch.distributed.run BEFORE any GPU call.  Without a GPU each rank stops at bench.py's own
+    "needs an MI355X" check -- which proves the ranks were started and probed the device themselves."""
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available():
+        pytest.skip("host-only check (on a GPU box the spawned ranks would run the whole bench)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--unet", "tiny"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    # rank 0 stops at the device probe; the elastic agent then ends rank 1 and lists both ranks in its report
+    assert "bench.py needs an MI355X" in p.stderr and "local_rank: 1" in p.stderr and "local_rank: 0" in p.stderr, p.stderr[-1500:]
+
+
+def test_random_exposure_adjust_is_hot_path_subset_only():
+    """Only the uint16 quantiser of the reference class is in scope; the training-time augmentation
+    members raise instead of computing on the host."""
+    from gm_diffusion import RandomExposureAdjust
+    from gm_diffusion._native import HipExtensionError
+    from gm_diffusion.stage1.augmentations import OutOfScopeError
+
+    aug = RandomExposureAdjust(gamma=2.2, prob=1.0)
+    with pytest.raises(OutOfScopeError):
+        aug(torch.zeros(3, 8, 8))
+    with pytest.raises(OutOfScopeError):
+        aug.hdr_to_ldr
+    with pytest.raises(HipExtensionError):  # the in-scope member is a HIP kernel: host tensors are refused
+        RandomExposureAdjust.discretize_to_uint16(torch.zeros(4))

@@ -165,3 +165,34 @@ def test_vae_decode_sliced_batch_equals_whole():
     parts, H2, W2 = m.decode_nhwc(z)
     assert (H, W) == (H2, W2) == (64, 64) and parts.shape == whole.shape
     assert rel_err(parts, whole) < 1e-5
+
+
+def test_sd15_vae_decode_small_latent():
+    """SD-1.5-width AutoencoderKL decoder (512/512/256/128 channels, the 512-channel single-head mid-block attention) on an
+    8x8 latent against the oracle: float32 <= 3e-5, bf16 <= 4e-2 (the full-width VAE was never compared)."""
+    from oracle import fixtures
+
+    ov = fixtures.build_vae("sd15")
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(19)) * 3
+    ref = ov.decode(z)[0]
+    assert ref.shape == (2, 3, 64, 64)
+    got = _hip_vae(ov, torch.float32).decode(z.to(DEV), return_dict=False)[0]
+    assert got.shape == ref.shape and rel_err(got, ref) < 3e-5
+    got_b = _hip_vae(ov, torch.bfloat16).decode(z.to(DEV), return_dict=False)[0]
+    assert rel_err(got_b.float(), ref) < 4e-2
+
+
+def test_sd15_unet_forward_f32_32x32_latent_cfg_batch():
+    """Full-width SD-1.5 UNet at the BASELINE config-1 latent size (32x32 = 1024 / 256 / 64 / 16 tokens per level), batch 2
+    (the CFG pair), two timesteps: float32 vs the oracle."""
+    from oracle import fixtures
+
+    ou = fixtures.build_unet("sd15", 8)
+    hu = _hip_unet(ou, torch.float32)
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(2, 8, 32, 32, generator=g)
+    ctx = torch.randn(2, 77, 768, generator=g)
+    for t in (901, 101):
+        ref = ou(x, torch.tensor(t), encoder_hidden_states=ctx)[0]
+        got = hu(x.to(DEV), t, encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
+        assert rel_err(got, ref) < 3e-5, t

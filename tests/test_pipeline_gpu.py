@@ -377,3 +377,134 @@ def test_dual_pipeline_other_token_counts(L):
     sb, gb = pb(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
                 num_inference_steps=4, guidance_scale=7.5, output_type="latent")
     assert rms(sb, rs) < 0.2 and rms(gb, rg) < 0.2 and torch.isfinite(sb).all()
+
+
+def _ddpm(**kw):
+    from gm_diffusion.components import DDPMScheduler
+
+    kw.setdefault("steps_offset", 1)
+    return DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", **kw)
+
+
+@pytest.mark.parametrize("hip_graphs,overlap", [(True, True), (False, False)])
+def test_dual_pipeline_ddpm_on_device_shared_generator(hip_graphs, overlap):
+    """SURVEY §8f-2 / VERDICT r1 item 1: DDPM is the scheduler the reference's Stage-3 CLI builds
+    (scripts/inference/generate_hdr.py:162) and the dual pipeline hands ONE generator to both scheduler steps
+    (stable_diffusion_dual_unet.py:1015, 1077, 1093): SDR noise is drawn before GM noise in every iteration.  HIP models +
+    fused gmd_ddpm_step (graphs + two streams, and eager single stream) against the oracle loop with the same CPU generator."""
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    pipe = _dual_pipe(torch.float32)
+    pipe.scheduler = _ddpm(clip_sample=False)
+    pipe.set_progress_bar_config(disable=True)
+    pipe.use_hip_graphs, pipe.overlap_streams = hip_graphs, overlap
+    pe, ne, lat = fixtures.make_inputs(2, 16, 16, cross_dim=64)
+    assert pipe._use_fused(lat.to(DEV), pipe.unet, pipe.scheduler)
+    sdr, gm = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+                   num_inference_steps=8, guidance_scale=7.5, generator=torch.Generator().manual_seed(123), output_type="latent")
+    rec = []
+    rs, rg = OP.dual_loop(fixtures.build_unet("tiny", 4), fixtures.build_unet("tiny", 8), OS.DDPMScheduler(), pe, ne, lat, 8,
+                          guidance_scale=7.5, generator=torch.Generator().manual_seed(123), record=rec)
+    assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL
+    # the two latents must NOT have received the same noise (a swapped / shared draw would still pass a loose tolerance)
+    assert rms(sdr, rg) > 0.1
+    # generic scheduler-protocol path (torch expressions of the reference loop on the HIP models): same generator order
+    pipe._use_fused = lambda *args: False
+    s2, g2 = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+                  num_inference_steps=8, guidance_scale=7.5, generator=torch.Generator().manual_seed(123), output_type="latent")
+    assert rms(s2, rs) <= RMS_TOL and rms(g2, rg) <= RMS_TOL
+
+
+def test_gm_pipeline_ddpm_on_device_matches_oracle():
+    """generate_hdr.py:162, 212-218: StableDiffusionGMPipeline with DDPMScheduler and a seeded generator."""
+    from gm_diffusion.components import AutoencoderKL, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionGMPipeline
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    ou = fixtures.build_unet("tiny", 8)
+    pipe = StableDiffusionGMPipeline(
+        vae=_hip(AutoencoderKL, fixtures.build_vae("tiny"), torch.float32), text_encoder=None, tokenizer=None,
+        unet=_hip(UNet2DConditionModel, ou, torch.float32), scheduler=_ddpm(clip_sample=False), safety_checker=None,
+        feature_extractor=None, requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    pe, ne, lat = fixtures.make_inputs(1, 16, 16, cross_dim=64)
+    sdr_lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(77))
+    out = pipe(sdr_lat.to(DEV), prompt=None, prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV),
+               num_inference_steps=10, guidance_scale=7.5, generator=torch.Generator().manual_seed(42), output_type="latent").images
+    ref = OP.gm_loop(ou, OS.DDPMScheduler(), sdr_lat, pe, ne, lat, 10, guidance_scale=7.5, generator=torch.Generator().manual_seed(42))
+    assert rms(out, ref) <= RMS_TOL
+
+
+@pytest.mark.parametrize("clip,vt", [(False, "fixed_small"), (True, "fixed_small"), (True, "fixed_small_log"), (False, "fixed_large")])
+def test_ddpm_step_kernel_bit_exact_vs_torch(clip, vt):
+    """gmd_ddpm_step against the torch expressions of DDPMScheduler.step over a whole trajectory (CFG + guidance rescale +
+    pipeline x0 + clipped posterior mean + variance noise): bit-identical, including the noise-free last step."""
+    from gm_diffusion import hip_ops as ops
+    from gm_diffusion.pipelines import rescale_noise_cfg
+
+    mk = lambda: _ddpm(clip_sample=clip, variance_type=vt, clip_sample_range=1.5, steps_offset=0)  # reaches t == 0: the step without noise
+    dev_s, host_s = mk(), mk()
+    dev_s.set_timesteps(7)
+    host_s.set_timesteps(7)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 4, 8, 8, generator=g)
+    xd = x.to(DEV)
+    gs, gr = 6.5, 0.3
+    for t in dev_s.timesteps.tolist():
+        eps2 = torch.randn(6, 4, 8, 8, generator=g)
+        u, c = eps2.chunk(2)
+        e = u + gs * (c - u)
+        e = rescale_noise_cfg(e, c, guidance_rescale=gr)
+        a = host_s.alphas_cumprod[t]
+        x0_ref = (x - (1 - a).sqrt() * e) / a.sqrt()
+        x_ref = host_s._host_step(e, t, x, generator=torch.Generator().manual_seed(100 + t), return_dict=False)[0]
+        xd_new, x0_dev = dev_s.fused_step(eps2.to(DEV), t, xd, True, gs, gr, want_x0=True, generator=torch.Generator().manual_seed(100 + t))
+        assert torch.equal(x0_dev.cpu(), x0_ref), t
+        assert torch.equal(xd_new.cpu(), x_ref), t
+        x, xd = x_ref, xd_new
+    assert t == 0
+
+
+def test_gm_pipeline_baseline_config1_full_width_vs_cpu_oracle():
+    """BASELINE.json configs[0] as stated: SD-v1-5-width single-UNet GM pipeline, 1 prompt, 256x256 (32x32 latent), 10 PNDM
+    steps (11 iterations at the CFG batch of 2), float32 -- the HIP pipeline against the CPU oracle run HERE at full width,
+    per-step and final latent RMS <= 1e-3 (north-star tolerance)."""
+    from gm_diffusion.components import AutoencoderKL, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionGMPipeline
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    ou = fixtures.build_unet("sd15", 8)
+    pe, ne, lat = fixtures.make_inputs(1, 32, 32)
+    sdr_lat = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(7)) * 0.7
+    rec = []
+    ref = OP.gm_loop(ou, OS.PNDMScheduler(), sdr_lat, pe, ne, lat, num_inference_steps=10, guidance_scale=7.5, record=rec)
+    pipe = StableDiffusionGMPipeline(
+        vae=_hip(AutoencoderKL, fixtures.build_vae("tiny"), torch.float32), text_encoder=None, tokenizer=None,
+        unet=_hip(UNet2DConditionModel, ou, torch.float32), scheduler=_pndm(), safety_checker=None, feature_extractor=None,
+        requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    steps = []
+    out = pipe(sdr_lat.to(DEV), prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV),
+               num_inference_steps=10, guidance_scale=7.5, output_type="latent",
+               callback_on_step_end=lambda p, i, t, kw: (steps.append(kw["latents"].cpu()) or {})).images
+    per_step = [rms(s_, rec[i]) for i, s_ in enumerate(steps)]
+    print("config-1 full width, per-step latent RMS:", ["%.1e" % v for v in per_step])
+    assert len(per_step) == 11 and max(per_step) <= RMS_TOL, per_step
+    assert rms(out, ref) <= RMS_TOL
+    # the bf16 path on the same inputs: drift is reported (BASELINE's throughput precision), gated loosely
+    pb = StableDiffusionGMPipeline(
+        vae=pipe.vae, text_encoder=None, tokenizer=None, unet=_hip(UNet2DConditionModel, ou, torch.bfloat16), scheduler=_pndm(),
+        safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    pb.set_progress_bar_config(disable=True)
+    ob = pb(sdr_lat.to(DEV), prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV),
+            num_inference_steps=10, guidance_scale=7.5, output_type="latent").images
+    d = rms(ob, ref)
+    print(f"config-1 full width, bf16 final latent RMS vs fp32 oracle: {d:.3e}")
+    assert d < 0.1 and torch.isfinite(ob).all()

@@ -1,10 +1,15 @@
 #!/usr/bin/env python
-"""Correctness + speed of GEMM kernel variants (GMD_GEMM_FORCE) against the default kernel, in one process."""
+"""Correctness + speed of GEMM kernel variants (gmd_gemm_plan_override) against the default kernel, in one process."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gm-diffusion_amd"))
 import torch
 from gm_diffusion import hip_ops as ops
+from gm_diffusion._native import lib
+
+
+def force(v=None):
+    lib().gmd_gemm_plan_override(*([int(x) for x in v.split(",")] if v else [0, 0, 0, 0]))
 
 variants = sys.argv[1:] or ["128,160,123,1", "128,160,124,1", "256,160,143,1", "128,160,122,1"]
 g = torch.Generator().manual_seed(0)
@@ -37,13 +42,13 @@ for M, N, K in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192
 
 print(f"{'case':52s} {'default':>16s} " + " ".join(f"{v:>22s}" for v in variants))
 for name, fl, fn in cases:
-    os.environ.pop("GMD_GEMM_FORCE", None)
+    force()
     ref = fn().float()
     t0 = timeit(fn)
     row = f"{name:52s} {t0:7.1f}us {fl / t0 / 1e6:6.0f}TF"
     for v in variants:
         bn_ok = True
-        os.environ["GMD_GEMM_FORCE"] = v
+        force(v)
         try:
             out = fn().float()
             err = float((out - ref).abs().max())
@@ -52,4 +57,4 @@ for name, fl, fn in cases:
         except Exception as e:
             row += f" {'n/a':>22s}"
     print(row, flush=True)
-os.environ.pop("GMD_GEMM_FORCE", None)
+force()
