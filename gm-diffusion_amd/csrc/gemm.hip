@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool CONV, int WM, int WN, int TN, int NST>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_ring_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void gemm_ring_kernel(const GemmParams p) {
     constexpr int NWAVES = WM * WN, TM = 4;
     constexpr int BM = WM * 64, BN = WN * TN * 16;
     constexpr int RPP = NWAVES * 8;                 // tile rows written per staging pass (8 rows per wave instruction)
@@ -1095,6 +1095,16 @@ int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipSt
         p.ksplit = pl.ksplit;
         p.ws = (float*)ws;
         const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
+        // the fused GEGLU epilogue pairs value / gate tiles of 16 columns inside a wave: only kernels with an even number of
+        // column tiles per wave implement it (the heuristic picks one; a plan override must not bypass that -- the plain
+        // epilogue would write [M, N] into the [M, N/2] output)
+        if (p.act == GMD_ACT_GEGLU) {
+            const bool ring_odd = pl.pf >= 100 ? (pl.bn == 160 || (pl.bm == 64 && pl.bn == 64)) : (pl.pf == 0 && pl.bm == 128 && pl.bn == 160);
+            if (ring_odd || pl.bn == 160 || pl.ksplit > 1) {
+                gmd_set_error("%s: plan %dx%d pf=%d ksplit=%d has no GEGLU epilogue", name, pl.bm, pl.bn, pl.pf, pl.ksplit);
+                return GMD_ERR_UNSUPPORTED;
+            }
+        }
         // pf 1xx selects a ring kernel (experiments): 1WS with W = waves-in-M (2|4), S = stages
         if (pl.pf == 143 && pl.bn == 160) e = launch_ring<CONV, 4, 2, 5, 3>(p, gz, s);
         else if (pl.pf == 143 && pl.bn == 128) e = launch_ring<CONV, 4, 2, 4, 3>(p, gz, s);
@@ -1104,6 +1114,10 @@ int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipSt
         else if (pl.pf == 122 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 2>(p, gz, s);
         else if (pl.pf == 123 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 3>(p, gz, s);
         else if (pl.pf == 124 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 4>(p, gz, s);
+        else if (pl.pf == 103 && pl.bm == 64 && pl.bn == 64) e = launch_ring<CONV, 1, 4, 1, 3>(p, gz, s);
+        else if (pl.pf == 104 && pl.bm == 64 && pl.bn == 64) e = launch_ring<CONV, 1, 4, 1, 4>(p, gz, s);
+        else if (pl.pf == 103 && pl.bm == 64 && pl.bn == 128) e = launch_ring<CONV, 1, 4, 2, 3>(p, gz, s);
+        else if (pl.pf == 104 && pl.bm == 64 && pl.bn == 128) e = launch_ring<CONV, 1, 4, 2, 4>(p, gz, s);
         else if (pl.pf >= 100) { gmd_set_error("%s: ring variant %d not instantiated for BN=%d", name, pl.pf, pl.bn); return GMD_ERR_UNSUPPORTED; }
         // default: two-stage LDS-DMA ring, 4 waves, two workgroups per CU (fastest of all variants measured on MI355X)
         else if (pl.pf == 0 && pl.bm == 128 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 2>(p, gz, s);

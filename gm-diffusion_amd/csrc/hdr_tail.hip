@@ -1,6 +1,8 @@
 // HDR tail kernels: decode post-process, gain-map recomposition (Eq. 1), tone-mapping
-// operators, gamut compression and the integer quantisers.  HBM-bound elementwise work:
-// 16-byte coalesced accesses, 4 pixels per thread, no LDS.
+// operators, gamut compression and the integer quantisers.  HBM-bound elementwise work, no LDS.
+// The pipeline's own input (the VAE decoder's float32 [B,HW,4] image) takes hdr_tail_vec4_kernel:
+// four pixels per thread, 16-byte loads, 16- / 8- / 4-byte stores of whole 12-element runs; the
+// other layouts (planar NCHW, packed RGB, bf16) take the generic one-pixel-per-thread kernel.
 //
 // Float arithmetic follows the reference's operation order with FMA contraction disabled
 // (this file is built with -ffp-contract=off) so results differ from torch-CPU only in the
@@ -74,6 +76,58 @@ __global__ __launch_bounds__(kThreads) void hdr_tail_kernel(
             const float hf = h / qp1;  // generate_hdr.py:28
             if (hdr_file) hdr_file[o] = hf;
             if (hdr_u16) hdr_u16[o] = (uint16_t)u16_code(hf);
+        }
+    }
+}
+
+// Fast path of the fused tail for float32 [B,HW,4] input (what AutoencoderKL.decode_nhwc produces): FOUR pixels per thread.
+// Loads are 16 bytes per pixel and operand; the 12 consecutive output elements of a thread are stored as three float4
+// (float images), three uint32 (u8 bytes) or three uint2 (u16 codes) -- whole aligned runs instead of stride-3 scalars.
+// Element arithmetic is the generic kernel's, expression for expression: both paths are bit-identical.
+__global__ __launch_bounds__(kThreads) void hdr_tail_vec4_kernel(
+    const float4* __restrict__ sdr_dec, const float4* __restrict__ gm_dec, int64_t npix4, float qmax, float eps, int flags,
+    float* __restrict__ sdr_img, float* __restrict__ gm_img, uint8_t* __restrict__ sdr_u8, uint8_t* __restrict__ gm_u8,
+    float* __restrict__ hdr, float* __restrict__ hdr_file, uint16_t* __restrict__ hdr_u16) {
+    const float qp1 = qmax + 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix4; i += (int64_t)gridDim.x * blockDim.x) {
+        float sv[12], gv[12], hv[12], hf[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 a = sdr_dec[i * 4 + k], b = gm_dec[i * 4 + k];
+            const float s3[3] = {a.x, a.y, a.z}, g3[3] = {b.x, b.y, b.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int e = 3 * k + c;
+                sv[e] = clamp01(s3[c] / 2.0f + 0.5f);  // generate_hdr.py:227
+                gv[e] = clamp01(g3[c] / 2.0f + 0.5f);  // generate_hdr.py:232
+                hv[e] = eq1(sv[e], gv[e], qmax, eps, flags & 1);
+                hf[e] = hv[e] / qp1;                   // generate_hdr.py:28
+            }
+        }
+        const int64_t o = i * 12;
+        auto st_f32 = [&](float* dst, const float (&v)[12]) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(dst + o + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        };
+        auto st_u8 = [&](uint8_t* dst, const float (&v)[12]) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                *reinterpret_cast<uint32_t*>(dst + o + 4 * k) = (uint32_t)u8_trunc(v[4 * k]) | ((uint32_t)u8_trunc(v[4 * k + 1]) << 8) |
+                                                                ((uint32_t)u8_trunc(v[4 * k + 2]) << 16) | ((uint32_t)u8_trunc(v[4 * k + 3]) << 24);
+        };
+        if (sdr_img) st_f32(sdr_img, sv);
+        if (gm_img) st_f32(gm_img, gv);
+        if (sdr_u8) st_u8(sdr_u8, sv);
+        if (gm_u8) st_u8(gm_u8, gv);
+        if (hdr) st_f32(hdr, hv);
+        if (hdr_file) st_f32(hdr_file, hf);
+        if (hdr_u16) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t c0 = (uint32_t)(uint16_t)u16_code(hf[4 * k]), c1 = (uint32_t)(uint16_t)u16_code(hf[4 * k + 1]);
+                const uint32_t c2 = (uint32_t)(uint16_t)u16_code(hf[4 * k + 2]), c3 = (uint32_t)(uint16_t)u16_code(hf[4 * k + 3]);
+                *reinterpret_cast<uint2*>(hdr_u16 + o + 4 * k) = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+            }
         }
     }
 }
@@ -196,7 +250,13 @@ int gmd_hdr_tail(const void* sdr_dec, const void* gm_dec, int in_dtype, int in_l
     if ((int64_t)B * HW == 0) return GMD_OK;
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for((int64_t)B * HW);
-    if (in_dtype == GMD_F32)
+    const auto al = [](const void* p, int a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; };
+    const bool vec4 = in_dtype == GMD_F32 && in_layout == 2 && ((int64_t)B * HW) % 4 == 0 && al(sdr_dec, 16) && al(gm_dec, 16) &&
+                      al(sdr_img, 16) && al(gm_img, 16) && al(hdr, 16) && al(hdr_file, 16) && al(sdr_u8, 4) && al(gm_u8, 4) && al(hdr_u16, 8);
+    if (vec4)
+        hdr_tail_vec4_kernel<<<grid_for((int64_t)B * HW / 4), kThreads, 0, s>>>((const float4*)sdr_dec, (const float4*)gm_dec, (int64_t)B * HW / 4, qmax,
+                                                                                eps, flags, sdr_img, gm_img, sdr_u8, gm_u8, hdr, hdr_file, hdr_u16);
+    else if (in_dtype == GMD_F32)
         hdr_tail_kernel<float><<<grid, kThreads, 0, s>>>((const float*)sdr_dec, (const float*)gm_dec, in_layout, B, HW, qmax, eps,
                                                          flags, sdr_img, gm_img, sdr_u8, gm_u8, hdr, hdr_file, hdr_u16);
     else

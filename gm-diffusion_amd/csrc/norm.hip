@@ -338,6 +338,69 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const T* __restrict
     }
 }
 
+// LayerNorm, packed form for the SD-1.5 widths: a row of C = 8 * LPR * CPL elements is shared by LPR lanes (8 / 16 / 32 for
+// C = 320 / 640 / 1280, five 16-byte chunks each), so one wave normalises 64 / LPR rows with EVERY lane busy -- the
+// one-wave-per-row form above leaves 24 of 64 lanes idle at C = 320.  Lane `sub` of a row owns chunks sub + LPR * k: one
+// wave-instruction reads LPR * 16 contiguous bytes of each of its rows.  Exact two-pass variance; the LPR-lane sums run on
+// the DPP path (quad permutes, row mirrors; one cross-row step for LPR = 32) in a fixed order.
+template <int LPR>
+__device__ __forceinline__ float lane_group_sum(float v) {
+    static_assert(LPR == 8 || LPR == 16 || LPR == 32, "lanes per row");
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    if (LPR >= 16) v += dpp_f32<0x140>(v);
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+template <typename T, int LPR, int CPL>
+__global__ __launch_bounds__(kThreads) void layernorm_packed_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int C,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float eps) {
+    constexpr int V = Elem<T>::kVec, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int64_t row = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;  // whole lane groups are live or dead: the DPP sums never mix rows
+    float v[CPL][V];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        if (live) {
+            load_vec(X + row * C + (int64_t)(sub + LPR * k) * V, v[k]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[k][j] = 0.0f;
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += v[k][j];
+    const float mean = lane_group_sum<LPR>(s) / (float)C;
+    float s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float d = v[k][j] - mean; s2 += d * d; }
+    const float rstd = rsqrtf(lane_group_sum<LPR>(s2) / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c0 = (sub + LPR * k) * V;
+        float ga[V], be[V], o[V];
+        load_vec(gamma + c0, *reinterpret_cast<float(*)[4]>(&ga[0]));
+        load_vec(beta + c0, *reinterpret_cast<float(*)[4]>(&be[0]));
+        if (V == 8) {
+            load_vec(gamma + c0 + 4, *reinterpret_cast<float(*)[4]>(&ga[V == 8 ? 4 : 0]));
+            load_vec(beta + c0 + 4, *reinterpret_cast<float(*)[4]>(&be[V == 8 ? 4 : 0]));
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = (v[k][j] - mean) * rstd * ga[j] + be[j];
+        store_vec(Y + row * C + c0, o);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row softmax (float32 logits -> T probabilities), one block per row, three passes.
 // ---------------------------------------------------------------------------------------------
@@ -509,8 +572,17 @@ int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C, const 
     const int grid = (int)((rows + 3) / 4);
     if (dtype == GMD_BF16) {
         GMD_REQUIRE(C % 8 == 0, "gmd_layernorm: C=%d must be a multiple of 8", C);
+        const bool vecp = gmd_aligned16(gamma) && gmd_aligned16(beta);
+#define GMD_LN_PACKED(LPR) layernorm_packed_kernel<bf16_t, LPR, 5><<<(int)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), kThreads, 0, s>>>( \
+    (const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps)
+        // SD-1.5 widths: every lane busy (LPR lanes per row, five 16-byte chunks each)
+        // (measured, tools/bench_graph_ops.py: 32768 x 320 12.8 -> 10.3 us, 8192 x 640 7.9 -> 7.5 us; at C = 1280 the
+        // 32-lane form needs a cross-row shuffle and LOSES to one wave per row, 4.9 -> 5.8 us, so it is not used there)
+        if (vecp && C == 320) GMD_LN_PACKED(8);
+        else if (vecp && C == 640) GMD_LN_PACKED(16);
+#undef GMD_LN_PACKED
         // narrow rows (one 16-byte chunk per lane) and many of them: four rows per wave keep four loads in flight
-        if (C <= 512 && rows >= 8192)
+        else if (C <= 512 && rows >= 8192)
             layernorm_kernel<bf16_t, 1, 4><<<(int)((rows + 15) / 16), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
         else if (C <= 1024 && rows >= 4096)
             layernorm_kernel<bf16_t, 2, 2><<<(int)((rows + 7) / 8), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);

@@ -99,6 +99,27 @@ def test_hdr_tail_fused_vs_oracle(layout, dtype):
     assert rel_err(out_c["hdr"], torch.from_numpy(ref_c)) < 2e-7
 
 
+def test_hdr_tail_vec4_path_bit_identical_to_generic():
+    """The four-pixels-per-thread fast path (float32 [B,HW,4] input, 16-byte accesses) against the generic kernel on the same
+    pixels given as packed RGB (layout 1) and with a pixel count that is not a multiple of 4 (generic again)."""
+    o = ops()
+    g = torch.Generator().manual_seed(13)
+    B, Hh, W = 3, 24, 40
+    s3 = (torch.rand(B, Hh * W, 3, generator=g) * 2.6 - 1.3)
+    g3 = (torch.rand(B, Hh * W, 3, generator=g) * 2.6 - 1.3)
+    pad = lambda x: torch.cat([x, torch.full_like(x[..., :1], -3.0)], -1).contiguous()
+    fast = o.hdr_tail(pad(s3).to(DEV), pad(g3).to(DEV), 2, B, Hh, W, qmax=99.0)
+    slow = o.hdr_tail(s3.to(DEV), g3.to(DEV), 1, B, Hh, W, qmax=99.0)
+    assert set(fast) == set(slow) and len(fast) == 7
+    for k in fast:
+        assert torch.equal(fast[k], slow[k]), k
+    # odd pixel count -> generic kernel for layout 2 as well
+    odd = o.hdr_tail(pad(s3)[:1, :957].contiguous().to(DEV), pad(g3)[:1, :957].contiguous().to(DEV), 2, 1, 1, 957, qmax=99.0, clamp=True)
+    ref = o.hdr_tail(s3[:1, :957].contiguous().to(DEV), g3[:1, :957].contiguous().to(DEV), 1, 1, 1, 957, qmax=99.0, clamp=True)
+    for k in odd:
+        assert torch.equal(odd[k], ref[k]), k
+
+
 def test_quantisers_bit_exact_large():
     o = ops()
     from oracle import hdr_ops as H
@@ -702,3 +723,25 @@ def test_attention_and_norm_fuzz():
         ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
         got = o.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), 1e-5)
         assert rel_err(got.float(), F.layer_norm(x.float(), (C,), ga, be, 1e-5)) < 1e-2, ("ln", rows, C)
+
+
+def test_plan_override_cannot_bypass_geglu_tile_rule():
+    """gmd_gemm_plan_override is a tuning hook; a forced tile whose kernel has no GEGLU epilogue must be refused, not
+    launched (the plain epilogue would write [M, N] into the [M, N/2] output)."""
+    from gm_diffusion._native import HipExtensionError, lib
+
+    o = ops()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(256, 320, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(640, 320, generator=g) * 0.05).bfloat16().to(DEV)
+    b = torch.randn(640, generator=g).to(DEV)
+    want = o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU)
+    try:
+        lib().gmd_gemm_plan_override(128, 160, 9, 1)
+        with pytest.raises(HipExtensionError):
+            o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU)
+        lib().gmd_gemm_plan_override(128, 128, 9, 1)  # an even-tile kernel: allowed, same result as the heuristic's choice
+        got = o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU)
+    finally:
+        lib().gmd_gemm_plan_override(0, 0, 0, 0)
+    assert rel_err(got.float(), want.float()) < 1e-2

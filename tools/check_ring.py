@@ -27,13 +27,15 @@ def timeit(fn, reps=20):
 cases = []
 for B, H, W, ci, co, kw in [(8, 64, 64, 320, 320, {}), (8, 64, 64, 640, 320, {}), (8, 32, 32, 640, 640, {}), (2, 33, 17, 128, 320, {}),
                             (8, 32, 32, 640, 640, dict(upsample=True)), (8, 64, 64, 320, 320, dict(stride=2)), (8, 16, 16, 1280, 1280, {}),
-                            (4, 128, 128, 512, 512, {}), (4, 256, 256, 256, 256, {})]:
+                            (4, 128, 128, 512, 512, {}), (4, 256, 256, 256, 256, {}), (4, 64, 64, 320, 320, {}), (4, 32, 32, 640, 640, {}),
+                            (8, 32, 32, 1280, 640, {}), (4, 16, 16, 1280, 1280, {}), (8, 8, 8, 1280, 1280, {})]:
     x = torch.randn(B, H * W, ci, generator=g).bfloat16().cuda()
     w = (torch.randn(co, 9 * ci, generator=g) * 0.02).bfloat16().cuda()
     b = torch.randn(co, generator=g).cuda()
     cases.append((f"conv B={B} {H}x{W} {ci}->{co} {kw}", 2.0 * B * H * W * co * 9 * ci / (kw.get('stride', 1) ** 2) * (4 if kw.get('upsample') else 1),
                   lambda x=x, w=w, b=b, B=B, H=H, W=W, kw=kw: ops.conv3x3(x, w, B, H, W, bias=b, **kw)[0]))
-for M, N, K in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 5120), (1000, 320, 192)]:
+for M, N, K in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 5120), (1000, 320, 192),
+                (16384, 320, 320), (4096, 640, 640), (1024, 1280, 1280), (8192, 1280, 640), (2048, 2560, 1280)]:
     a = torch.randn(M, K, generator=g).bfloat16().cuda()
     w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
     b = torch.randn(N, generator=g).cuda()

@@ -47,6 +47,9 @@ def main():
     ops.gemm_nt = wrap("gemm", orig_gemm, lambda a_, w, **kw: f"M={a_.shape[-2]} N={w.shape[-2]} K={a_.shape[-1]} b={(a_.shape[0] if a_.dim()==3 else (w.shape[0] if w.dim()==3 else 1))}")
     ops.conv3x3 = wrap("conv", orig_conv, lambda x, w, B, H, W, **kw: f"B={B} {H}x{W} Cin={x.shape[-1]} Cout={w.shape[0]} s={kw.get('stride',1)} up={int(kw.get('upsample',False))}")
     ops.attention = wrap("attn", orig_attn, lambda q, k, vt, heads, nk, scale, **kw: f"B={q.shape[0]} Nq={q.shape[1]} Nk={nk} d={vt.shape[1]//heads}")
+    ops.groupnorm = wrap("gn", ops.groupnorm, lambda x, B, G, *a_, **kw: f"B={B} rows={x.numel() // (B * x.shape[-1])} C={x.shape[-1]} silu={int(kw.get('silu', False))}")
+    ops.layernorm = wrap("ln", ops.layernorm, lambda x, *a_, **kw: f"rows={x.numel() // x.shape[-1]} C={x.shape[-1]}")
+    ops.concat_channels = wrap("cat", ops.concat_channels, lambda a_, b_: f"rows={a_.numel() // a_.shape[-1]} C={a_.shape[-1]}+{b_.shape[-1]}")
     import gm_diffusion.components.unet_2d_condition as U
     import gm_diffusion.components.autoencoder_kl as V
     dtype = torch.bfloat16
@@ -84,8 +87,8 @@ def main():
         summ = timer.summary()
         ksum = sum(v["ms"] for v in summ.values()) / a.reps
         print(f"\n=== {name}: {total:.3f} ms per call; timed gemm/conv/attn kernels {ksum:.3f} ms ===")
-        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:60]:
-            print(f"{k:62s} n={v['launches']//a.reps:3d} avg_us={v['avg_us']:9.1f} tot_ms={v['ms']/a.reps:8.3f} TF/s={v['tflops']:7.1f}")
+        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:90]:
+            print(f"{k:62s} n={v['launches']//a.reps:3d} avg_us={v['avg_us']:9.1f} tot_ms={v['ms']/a.reps:8.3f} TF/s={v['tflops']:7.1f} GB/s={v['gbps']:7.0f}")
 
 
 if __name__ == "__main__":
