@@ -484,7 +484,17 @@ class UNet2DConditionModel(_HipModule):
         for t in self._transformers:
             self._cross_kv(t, ehs)
 
-    def _transformer(self, t, x, B, H, W, ehs):
+    @staticmethod
+    def _dup_batch(t):
+        """[B, ...] -> [2B, ...] (two device-to-device copies; memory plumbing only)."""
+        out = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[: t.shape[0]].copy_(t)
+        out[t.shape[0]:].copy_(t)
+        return out
+
+    def _transformer(self, t, x, B, H, W, ehs, cfg_dup=False):
+        """``cfg_dup``: x holds the B UNIQUE samples of a classifier-free-guidance pair whose two halves differ only in the
+        text conditioning; everything up to the cross-attention query is computed once, then duplicated (returns 2B rows)."""
         C = x.shape[-1]
         N = H * W
         heads = self.config.attention_head_dim
@@ -498,6 +508,9 @@ class UNet2DConditionModel(_HipModule):
         # cross-attention over the text tokens
         n2 = ops.layernorm(h, *t["norm2"])
         q = ops.gemm_nt(n2, t["q2"]).view(B, N, C)
+        if cfg_dup:  # first use of the text conditioning: from here on the two halves differ
+            q, h, x = self._dup_batch(q), self._dup_batch(h.view(B, N, C)).view(2 * B * N, C), self._dup_batch(x)
+            B *= 2
         kc, vtc = self._cross_kv(t, ehs)
         L = ehs.shape[1]
         if self._dtype == torch.bfloat16:
@@ -527,26 +540,45 @@ class UNet2DConditionModel(_HipModule):
         self._ensure()
         self._t_dev.copy_(ts_dev[i:i + 1], non_blocking=True)
 
-    def forward_packed(self, x, B, H, W, encoder_hidden_states):
+    def supports_cfg_shared(self):
+        """True when the first down block has a transformer (SD-1.5): the prefix shared by a CFG pair ends at its
+        cross-attention."""
+        return self.config.down_block_types[0].startswith("CrossAttn")
+
+    def forward_packed(self, x, B, H, W, encoder_hidden_states, cfg_shared=False):
         """x: packed channels-last input [B, H*W, cin_pad]; the timestep must already be in ``_t_dev``.
-        Returns float32 eps [B, out_channels, H, W].  Stream-ordered, allocation via torch only."""
+        Returns float32 eps [B, out_channels, H, W].  Stream-ordered, allocation via torch only.
+
+        ``cfg_shared``: classifier-free guidance evaluates the SAME latents twice and only the text conditioning differs
+        (stable_diffusion_dual_unet.py:1045-1047 ``torch.cat([latents] * 2)``).  Nothing before the first cross-attention
+        reads the conditioning, so conv_in, the first ResnetBlock2D and the first transformer's GroupNorm / proj_in / whole
+        self-attention / cross-attention query are computed ONCE on the B/2 unique samples (x then has B/2 rows, B is still
+        the row count of ``encoder_hidden_states`` and of the result) and duplicated there: the full-resolution
+        self-attention -- the longest kernel of the forward -- runs at half the batch."""
         w = self._w
         c = self.config
         eps = c.norm_eps
         ehs = encoder_hidden_states
         if ehs.dtype != self._dtype:
             raise HipExtensionError("encoder_hidden_states must already be in the UNet dtype (use prepare_context)")
+        if cfg_shared and (B % 2 or not self.supports_cfg_shared()):
+            raise HipExtensionError("cfg_shared needs an even batch and a transformer in the first down block")
         te = ops.timestep_embedding(self._t_dev, B, c.block_out_channels[0], self._dtype, c.flip_sin_to_cos, c.freq_shift)
         te = ops.gemm_nt(te, w["te1"][0], bias=w["te1"][1], act=ops.ACT_SILU)
         temb = ops.gemm_nt(te, w["te2"][0], bias=w["te2"][1], act=ops.ACT_SILU)  # = silu(temb): the only use of temb
         temb = ops.gemm_nt(temb, w["te_all"][0], bias=w["te_all"][1], out_dtype=torch.float32)  # [B, sum(Cout)] f32
-        x, _, _ = ops.conv3x3(x, w["conv_in"][0], B, H, W, bias=w["conv_in"][1])
+        Bc = B // 2 if cfg_shared else B  # rows currently carried (the unique half until the first cross-attention)
+        x, _, _ = ops.conv3x3(x, w["conv_in"][0], Bc, H, W, bias=w["conv_in"][1])
         skips = [(x, H, W)]
         for blk in w["down"]:
             for j, r in enumerate(blk["res"]):
-                x = self._resnet(r, x, B, H, W, temb, eps)
+                x = self._resnet(r, x, Bc, H, W, temb[:Bc], eps)  # (both halves share the timestep: temb rows are identical)
                 if "attn" in blk:
-                    x = self._transformer(blk["attn"][j], x, B, H, W, ehs)
+                    dup = Bc != B
+                    x = self._transformer(blk["attn"][j], x, Bc, H, W, ehs, cfg_dup=dup)
+                    if dup:
+                        skips = [(self._dup_batch(s_), h_, w_) for s_, h_, w_ in skips]
+                        Bc = B
                 skips.append((x, H, W))
             if "ds" in blk:
                 x, H, W = ops.conv3x3(x, blk["ds"][0], B, H, W, bias=blk["ds"][1], stride=2)
@@ -566,7 +598,7 @@ class UNet2DConditionModel(_HipModule):
         y, _, _ = ops.conv3x3(x, w["conv_out"][0], B, H, W, bias=w["conv_out"][1], out_dtype=torch.float32)
         return ops.unpack_nchw(y, B, c.out_channels, H, W)
 
-    def graphed_forward(self, B, H, W, ehs):
+    def graphed_forward(self, B, H, W, ehs, cfg_shared=False):
         """Capture ``forward_packed`` for this (batch, latent size) into a HIP graph (one per shape, cached).
         Returns an object with ``.x`` (static packed-input buffer: fill it with ``pack_input(..., out=g.x)``) and
         ``.replay()`` -> float32 eps [B, out_channels, H, W] (static output buffer).  The timestep is read from the
@@ -574,7 +606,7 @@ class UNet2DConditionModel(_HipModule):
         ``update_context`` -- both outside the graph, so one capture serves every step and every prompt."""
         self._ensure()
         self.update_context(ehs)
-        key = (B, H, W, tuple(ehs.shape))
+        key = (B, H, W, tuple(ehs.shape), bool(cfg_shared))
         g = self._graphs.get(key)
         if g is not None:
             return g
@@ -583,14 +615,14 @@ class UNet2DConditionModel(_HipModule):
         if profiling.active() is not None:
             raise HipExtensionError("graph capture with an active KernelTimer is not supported")
         g = _GraphedForward()
-        g.x = torch.empty((B, H * W, self._cin_pad), dtype=self._dtype, device=self._device)
+        g.x = torch.empty((B // 2 if cfg_shared else B, H * W, self._cin_pad), dtype=self._dtype, device=self._device)
         g.x.zero_()
         cur = torch.cuda.current_stream(self._device)
         side = torch.cuda.Stream(device=self._device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):  # warm-up on a side stream: one-time attribute calls, workspaces, allocator pools
             for _ in range(2):
-                self.forward_packed(g.x, B, H, W, ehs)
+                self.forward_packed(g.x, B, H, W, ehs, cfg_shared=cfg_shared)
         cur.wait_stream(side)
         torch.cuda.synchronize(self._device)
         g.graph = torch.cuda.CUDAGraph()
@@ -598,7 +630,7 @@ class UNet2DConditionModel(_HipModule):
         self._capturing = True
         try:
             with ops.workspace_scope(g.ws), torch.cuda.graph(g.graph):
-                g.out = self.forward_packed(g.x, B, H, W, ehs)
+                g.out = self.forward_packed(g.x, B, H, W, ehs, cfg_shared=cfg_shared)
         finally:
             self._capturing = False
         while len(self._graphs) >= self.max_cached_graphs:  # oldest first: a graph pins its activations pool and 96 MB of scratch

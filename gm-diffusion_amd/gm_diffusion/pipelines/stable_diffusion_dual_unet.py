@@ -136,8 +136,10 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
             ts_host = [int(v) for v in timesteps.tolist()]          # host copy: no device sync inside the loop
             ts_dev = timesteps.to(device=latents.device, dtype=torch.float32)
             g_sdr = g_gm = None
+            shared = self._cfg_shared(self.unet, do_cfg)
+            nb_sdr = (2 if do_cfg else 1) * latents.shape[0]
             if self._graphs_ok():
-                g_sdr = self.unet.graphed_forward((2 if do_cfg else 1) * latents.shape[0], h, w, ctx)
+                g_sdr = self.unet.graphed_forward(nb_sdr, h, w, ctx, cfg_shared=shared)
                 g_gm = self.gm_unet.graphed_forward(latents.shape[0], h, w, gm_ctx)
             gm_stream.wait_stream(sdr_stream)
             if gm_stream is not sdr_stream:
@@ -150,9 +152,9 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                 if self.interrupt:
                     continue
                 if fused:
-                    x = self.unet.pack_input(latents, dup=2 if do_cfg else 1, out=g_sdr.x if g_sdr else None)
+                    x = self.unet.pack_input(latents, dup=2 if (do_cfg and not shared) else 1, out=g_sdr.x if g_sdr else None)
                     self.unet.set_timestep_from(ts_dev, i)
-                    sdr_noise_pred = g_sdr.replay() if g_sdr else self.unet.forward_packed(x, x.shape[0], h, w, ctx)
+                    sdr_noise_pred = g_sdr.replay() if g_sdr else self.unet.forward_packed(x, nb_sdr, h, w, ctx, cfg_shared=shared)
                     pre_step = latents
                     latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, ts_host[i], pre_step, do_cfg, self.guidance_scale,
                                                                    self.guidance_rescale if do_cfg else 0.0, want_x0=True,

@@ -299,6 +299,12 @@ class _GMPipelineBase(DiffusionPipeline):
         return torch.float32 if torch.device(device).type == "cuda" else prompt_embeds.dtype
 
     use_hip_graphs = True  # capture each UNet forward once per shape and replay it (device path only)
+    # classifier-free guidance feeds the UNet the same latents twice (stable_diffusion_gm.py:1047): the layers in front of the
+    # first cross-attention are evaluated once and duplicated (UNet2DConditionModel.forward_packed, ``cfg_shared``)
+    share_cfg_prefix = True
+
+    def _cfg_shared(self, unet, do_cfg):
+        return bool(do_cfg and self.share_cfg_prefix and unet.supports_cfg_shared())
 
     def _graphs_ok(self):
         from .. import profiling
@@ -418,7 +424,9 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
             ts_host = [int(v) for v in timesteps.tolist()]          # host copy: no device sync inside the loop
             ts_dev = timesteps.to(device=latents.device, dtype=torch.float32)
             hw = latents.shape[-2:]
-            graph = self.unet.graphed_forward((2 if do_cfg else 1) * latents.shape[0], hw[0], hw[1], ctx) if self._graphs_ok() else None
+            shared = self._cfg_shared(self.unet, do_cfg)
+            nb = (2 if do_cfg else 1) * latents.shape[0]
+            graph = self.unet.graphed_forward(nb, hw[0], hw[1], ctx, cfg_shared=shared) if self._graphs_ok() else None
 
         with self.progress_bar(total=num_inference_steps) as progress_bar:
             for i, t in enumerate(timesteps):
@@ -426,9 +434,9 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
                     continue
                 if fused:
                     # concat(sdr, gm) + CFG duplicate + cast fused into the input pack; CFG/rescale/PLMS in one kernel
-                    x = self.unet.pack_input((sdr_f32, latents), dup=2 if do_cfg else 1, out=graph.x if graph else None)
+                    x = self.unet.pack_input((sdr_f32, latents), dup=2 if (do_cfg and not shared) else 1, out=graph.x if graph else None)
                     self.unet.set_timestep_from(ts_dev, i)
-                    noise_pred = graph.replay() if graph else self.unet.forward_packed(x, x.shape[0], hw[0], hw[1], ctx)
+                    noise_pred = graph.replay() if graph else self.unet.forward_packed(x, nb, hw[0], hw[1], ctx, cfg_shared=shared)
                     latents, _ = self.scheduler.fused_step(noise_pred, ts_host[i], latents, do_cfg, self.guidance_scale,
                                                            self.guidance_rescale if do_cfg else 0.0,
                                                            **self._fused_step_kwargs(extra_step_kwargs))

@@ -196,3 +196,30 @@ def test_sd15_unet_forward_f32_32x32_latent_cfg_batch():
         ref = ou(x, torch.tensor(t), encoder_hidden_states=ctx)[0]
         got = hu(x.to(DEV), t, encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
         assert rel_err(got, ref) < 3e-5, t
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_unet_cfg_shared_prefix_equals_duplicated_batch(dtype, tol):
+    """Classifier-free guidance evaluates the same latents under two text conditionings (stable_diffusion_dual_unet.py:1045-
+    1047): computing the layers in front of the first cross-attention once (``cfg_shared``) must give what the duplicated
+    batch gives, for both halves, and against the oracle on the duplicated batch."""
+    from oracle import fixtures
+
+    ou = fixtures.build_unet("tiny", 4)
+    hu = _hip_unet(ou, dtype)
+    g = torch.Generator().manual_seed(23)
+    lat = torch.randn(3, 4, 16, 16, generator=g)
+    ctx = torch.randn(6, 77, ou.config.cross_attention_dim, generator=g)  # [uncond x3, cond x3]
+    ref = ou(torch.cat([lat, lat]), torch.tensor(601), encoder_hidden_states=ctx)[0]
+    hu._ensure()
+    c = hu.prepare_context(ctx.to(DEV))
+    hu.set_timestep(601)
+    full = hu.forward_packed(hu.pack_input(lat.to(DEV), dup=2), 6, 16, 16, c)
+    shared = hu.forward_packed(hu.pack_input(lat.to(DEV), dup=1), 6, 16, 16, c, cfg_shared=True)
+    assert shared.shape == full.shape == (6, 4, 16, 16)
+    assert rel_err(shared, full) < tol and rel_err(shared, ref) < max(tol, 3e-5 if dtype == torch.float32 else 3e-2)
+    assert not torch.equal(shared[:3], shared[3:])  # the halves do differ (different conditioning)
+    # captured-graph form: same numbers as the eager shared path, bit for bit
+    gph = hu.graphed_forward(6, 16, 16, c, cfg_shared=True)
+    hu.pack_input(lat.to(DEV), dup=1, out=gph.x)
+    assert torch.equal(gph.replay(), shared)
