@@ -41,6 +41,10 @@ struct GemmParams {
     float* ws;
     // conv3x3 geometry (CONV instantiations only)
     int Hin, Win, Cin, Hout, Wout, stride, upsample, pad_lo;
+    // conv3x3 K order of the ring kernel: channels are walked in blocks of `cblk` (a multiple of 64 dividing Cin), all nine
+    // taps of a block before the next block.  cblk == Cin is the plain tap-major order.  A smaller block keeps the rows an
+    // XCD re-reads for the next tap inside its 4 MiB L2 (see gmd_conv3x3).
+    int cblk;
 };
 
 // Row-invariant part of the A address of one staging slot.
@@ -792,12 +796,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
     const int per = (nk_total + p.ksplit - 1) / p.ksplit;
     const int kt_begin = ks * per;
     const int nk = (kt_begin + per <= nk_total ? per : nk_total - kt_begin);
-    int tap = 0, c0 = 0;
+    int tap = 0, c0 = 0, cb0 = 0;  // filter tap / channel of the K step being LOADED, first channel of its channel block
     bool newtap = true;
     if (CONV) {
-        const int kb = kt_begin * BK;
-        tap = kb / p.Cin;
-        c0 = kb - tap * p.Cin;
+        const int sb = p.cblk / BK, per_cb = 9 * sb;  // K steps per (block, tap) / per channel block
+        const int cbi = kt_begin / per_cb, rem = kt_begin - cbi * per_cb;
+        tap = rem / sb;
+        cb0 = cbi * p.cblk;
+        c0 = cb0 + (rem - tap * sb) * BK;
     }
 
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
 #pragma clang diagnostic pop
     };
     auto dma_tile = [&](int kt, int stage_idx) {
-        const unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
+        unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
         unsigned abytes = kbytes;
         if (CONV) {
             if (newtap) {
@@ -833,6 +839,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
                 newtap = false;
             }
             abytes = (unsigned)c0 * 2u;
+            kbytes = (unsigned)(tap * p.Cin + c0) * 2u;  // weights are [Cout][tap][Cin]
         }
         const unsigned stage = lds_base + (unsigned)stage_idx * kStage + (unsigned)wuni * (8 * 128);
 #pragma unroll
@@ -843,7 +850,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
         }
         if (CONV) {
             c0 += BK;
-            if (c0 >= p.Cin) { c0 = 0; ++tap; newtap = true; }
+            if (c0 >= cb0 + p.cblk) {  // next tap of this channel block, or the first tap of the next block
+                c0 = cb0;
+                ++tap;
+                newtap = true;
+                if (tap == 9) { tap = 0; cb0 += p.cblk; c0 = cb0; }
+            }
         }
     };
     // wait until all but `ahead` of this wave's tile DMA groups have landed (a group = NA + NW or NA + NW - 1 loads)
@@ -992,6 +1004,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 struct Plan {
     int bm, bn, pf, ksplit;
 };
+
+// Channel block of the ring kernel's conv3x3 K order.  The tiles resident on one XCD (64 = 32 CUs x 2 workgroups, a
+// contiguous run of the n-fastest tile order) read the same input rows once per filter tap; walking ALL channels of a tap
+// before the next tap makes the re-read distance rows x Cin x 2 bytes, which for Cin >= 640 at 64x64 (5.2 MB) no longer
+// fits the XCD's 4 MiB L2 (rocprofv3 FETCH_SIZE: 9.1x the algorithmic reads on 8x64x64 640->320,
+// profiles/r01_pmc_conv_attention_current.txt).  Blocks of `cblk` channels bring the distance back under ~2.5 MB.
+int conv_channel_block(int B, int Hin, int Win, int Cin, int Cout, int dtype) {
+    if (dtype != GMD_BF16) return Cin;
+    const int64_t rows_total = (int64_t)B * Hin * Win;
+    const int tiles_n = (Cout + 159) / 160;
+    const int64_t rows_resident = (int64_t)(64 / tiles_n > 0 ? 64 / tiles_n : 1) * 128;  // input rows under one XCD's resident tiles
+    const int64_t rows = rows_total / 8 < rows_resident ? (rows_total + 7) / 8 : rows_resident;
+    const int64_t budget = (5ll << 20) / 2;
+    if (rows * Cin * 2 <= budget) return Cin;
+    int best = 64;
+    for (int d = 64; d < Cin; d += 64)
+        if (Cin % d == 0 && rows * d * 2 <= budget) best = d;
+    return best;
+}
 
 struct Force {
     int bm = 0, bn = 0, pf = 0, ks = 0;
@@ -1195,6 +1226,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.ldrb = ldrb > 0 ? ldrb : N;
     p.residual = residual; p.ldr = ldr; p.sR = strideR; p.alpha = alpha; p.act = act;
     p.out_f32 = out_dtype == GMD_F32;
+    p.cblk = K;
     return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
 }
 
@@ -1232,6 +1264,7 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     p.residual = residual; p.ldr = Cout; p.alpha = 1.0f; p.act = GMD_ACT_NONE;
     p.out_f32 = out_dtype == GMD_F32;
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.upsample = upsample; p.pad_lo = pad_lo;
+    p.cblk = conv_channel_block(B, Hin, Win, Cin, Cout, dtype);
     return launch<true>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
 }
 
