@@ -278,174 +278,6 @@ __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm(+SiLU) in ONE launch for the UNet's large activations (where the per-group slab is too big for
-// gn_fused_kernel): grid (nb, B); workgroup (j, b) owns R whole pixel rows of sample b -- row-contiguous, 16-byte
-// accesses -- and keeps them in REGISTERS between the statistics and the normalisation, so the activation is read once
-// and written once (the split path reads it twice and needs two launches).
-//   phase 1  load the rows, per-thread per-channel sums -> LDS -> per-group {sum, sumsq} of this workgroup -> part[b][j][g]
-//   barrier  the nb workgroups of ONE sample meet on a device-scope counter (agent-scope release / acquire, relaxed poll:
-//            cdna_hip_programming.md Guideline 16); samples do not wait for each other
-//   phase 2  every workgroup folds the sample's nb partials (8 lanes per group, fixed order: deterministic, the same fold
-//            as gn_apply_ws_kernel), builds scale / shift in LDS and normalises its registers
-// Residency: the host only takes this path when nb <= 256 and nb * B <= 1024 workgroups (<= 4 per CU) -- a sample's
-// workgroups then all fit on the chip beside whatever else is running; the spin is bounded and the counters (zero at
-// rest, reset by the last workgroup to leave the barrier) live in a per-stream / per-graph buffer, so concurrent launches
-// on other streams never share them.
-// Thread map: column chunk (16 bytes) cx + CVB * cb, rows py + PY * i -- a thread's chunks sit at FIXED channel positions,
-// so its channel sums accumulate in registers (no LDS atomics: bit-reproducible).
-// ---------------------------------------------------------------------------------------------
-template <typename T, int NCB, int RPT>  // column blocks x row slots per thread: NCB * RPT 16-byte vectors live in registers
-// (<= 128 VGPRs: four workgroups per CU, the residency the host-side plan counts on)
-__global__ __launch_bounds__(kThreads, 4) void gn_onepass_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t HW, int C, int G,
-                                                              int R, int CVB, float eps, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, int silu, float* part, unsigned* sync) {
-    constexpr int V = Elem<T>::kVec;
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // phase 1: [PY][C] sums + [PY][C] sumsq; phase 2: [C][2] scale / shift
-    __shared__ float s_mean[64], s_rstd[64];
-    const int b = blockIdx.y, j = blockIdx.x, nb = gridDim.x;
-    const int PY = kThreads / CVB;
-    const int py = (int)threadIdx.x / CVB, cx = (int)threadIdx.x - py * CVB;
-    const bool act = py < PY;
-    const int64_t r0 = (int64_t)j * R;
-    const T* Xb = X + ((int64_t)b * HW) * C;
-    T* Yb = Y + ((int64_t)b * HW) * C;
-    uint4 v[NCB][RPT];
-    float* s_sum = smem;
-    float* s_sq = smem + (size_t)PY * C;
-    auto unpack = [](const uint4& w, float (&f)[V]) {
-        if (sizeof(T) == 2) {
-            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { f[(2 * e) % V] = __uint_as_float(ww[e] << 16); f[(2 * e + 1) % V] = __uint_as_float(ww[e] & 0xffff0000u); }
-        } else {
-            f[0] = __uint_as_float(w.x); f[1 % V] = __uint_as_float(w.y); f[2 % V] = __uint_as_float(w.z); f[3 % V] = __uint_as_float(w.w);
-        }
-    };
-    // ---- phase 1: load (all loads of the workgroup in flight before the first use) + per-channel sums --------------
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int rr = py + PY * i;
-            const int64_t row = r0 + rr;
-            v[cb][i] = (act && rr < R && row < HW) ? *reinterpret_cast<const uint4*>(Xb + row * C + (int64_t)(cb * CVB + cx) * V) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        float a[V], q[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) a[e] = q[e] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {  // rows beyond R / HW hold zeros: they add nothing
-            float f[V];
-            unpack(v[cb][i], f);
-#pragma unroll
-            for (int e = 0; e < V; ++e) { a[e] += f[e]; q[e] += f[e] * f[e]; }
-        }
-        if (act) {
-            const int c0 = (cb * CVB + cx) * V;
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                s_sum[(size_t)py * C + c0 + e] = a[e];
-                s_sq[(size_t)py * C + c0 + e] = q[e];
-            }
-        }
-    }
-    __syncthreads();
-    const int cpg = C / G;
-    if ((int)threadIdx.x < G) {
-        const int g = threadIdx.x;
-        double s = 0.0, s2 = 0.0;
-        for (int r = 0; r < PY; ++r)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += s_sum[(size_t)r * C + c]; s2 += s_sq[(size_t)r * C + c]; }
-        float* o = part + (((int64_t)b * nb + j) * G + g) * 2;
-        o[0] = (float)s;
-        o[1] = (float)s2;
-    }
-    // ---- per-sample barrier (Guideline 16: drain every storing wave, workgroup barrier, ONE agent-scope release, flag) ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned* arrive = sync + 2 * b;
-    unsigned* depart = arrive + 1;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 24)) break;  // bounded: a lost workgroup ends in wrong numbers, never in a hung GPU
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    // ---- phase 2: fold the sample's partials (fixed order), scale / shift, normalise from registers ----
-    for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
-        const int g = g0 + (int)threadIdx.x / 8, sub = threadIdx.x & 7;
-        double s = 0.0, s2 = 0.0;
-        if (g < G) {
-            for (int k = sub; k < nb; k += 8) {
-                const float2 o = *reinterpret_cast<const float2*>(part + (((int64_t)b * nb + k) * G + g) * 2);
-                s += o.x; s2 += o.y;
-            }
-        }
-        s = group8_sum(s);
-        s2 = group8_sum(s2);
-        if (g < G && sub == 0) {
-            const double n = (double)HW * cpg;
-            const double mean = s / n;
-            double var = s2 / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            s_mean[g] = (float)mean;
-            s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
-        }
-    }
-    __syncthreads();  // also: everyone is done with the phase-1 LDS image and with this sample's partials
-    if (threadIdx.x == 0) {
-        // the last workgroup to leave the barrier puts the counters back to zero for the next launch on this stream (every
-        // other workgroup of the sample has left its poll loop by then: it adds to `depart` only after the loop)
-        if (__hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1) {
-            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    float* ss = smem;
-    for (int c = threadIdx.x; c < C; c += kThreads) {
-        const int g = c / cpg;
-        const float sc = s_rstd[g] * gamma[c];
-        ss[2 * c] = sc;
-        ss[2 * c + 1] = beta[c] - s_mean[g] * sc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        const int chunk = cb * CVB + cx;
-        const float* qq = ss + (size_t)chunk * V * 2;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int rr = py + PY * i;
-            const int64_t row = r0 + rr;
-            if (act && rr < R && row < HW) {
-                float f[V];
-                unpack(v[cb][i], f);
-#pragma unroll
-                for (int e = 0; e < V; e += 2) {
-                    const float4 t = *reinterpret_cast<const float4*>(qq + 2 * e);
-                    f[e] = f[e] * t.x + t.y;
-                    f[e + 1] = f[e + 1] * t.z + t.w;
-                }
-                if (silu) {
-#pragma unroll
-                    for (int e = 0; e < V; ++e) f[e] = silu_f(f[e]);
-                }
-                store_vec(Yb + row * C + (int64_t)chunk * V, f);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers, exact two-pass variance.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int MAXCH, int ROWS>
@@ -727,79 +559,6 @@ int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, in
     }
 #undef GMD_GN_FUSED
     GMD_CHECK_LAUNCH("gmd_groupnorm_fused");
-    return GMD_OK;
-}
-
-// Plan of the single-launch kernel for a [B, HW, C] activation: 0 when the shape does not qualify (caller falls back to
-// gmd_groupnorm_fused / _split).  Outputs: rows per workgroup, 16-byte column chunks per thread block column (CVB),
-// column blocks (NCB), workgroups per sample (nb).
-static int gn_onepass_plan(int dtype, int B, int64_t HW, int C, int G, int* R_, int* CVB_, int* NCB_, int* nb_) {
-    const int V = dtype == GMD_BF16 ? 8 : 4;
-    if (C % V || C % G || G > 64 || HW < 64) return 0;
-    const int CV = C / V;
-    int best_cvb = 0, best_use = 0, best_ncb = 0;
-    for (int ncb = 1; ncb <= 8; ncb *= 2) {
-        if (CV % ncb) continue;
-        const int cvb = CV / ncb;
-        if (cvb > kThreads) continue;
-        const int use = (kThreads / cvb) * cvb;
-        if (use > best_use) { best_use = use; best_cvb = cvb; best_ncb = ncb; }
-    }
-    if (!best_cvb) return 0;
-    const int PY = kThreads / best_cvb;
-    // register-resident 16-byte vectors per thread: 8 for bf16 (106-112 VGPRs; 16 would spill under the 128-VGPR bound that
-    // keeps four workgroups on a CU), 16 for float32 (126 VGPRs)
-    const int kMaxVec = dtype == GMD_BF16 ? 8 : 16;
-    int rpt = kMaxVec / best_ncb;  // row slots per thread
-    if (rpt < 1) return 0;
-    int R = rpt * PY;
-    int64_t nb = (HW + R - 1) / R;
-    // no more workgroups than needed to put ~2 on every CU: fewer, fatter workgroups mean fewer partials to fold
-    while (nb * B < 256 && rpt > 1) { rpt = (rpt + 1) / 2; R = rpt * PY; nb = (HW + R - 1) / R; }
-    if (nb > 256 || nb * B > 1024 || nb < 2) return 0;
-    if ((size_t)PY * C * 2 * sizeof(float) > 64 * 1024) return 0;
-    *R_ = R; *CVB_ = best_cvb; *NCB_ = best_ncb; *nb_ = (int)nb;
-    return 1;
-}
-
-int gmd_groupnorm_onepass_query(int dtype, int B, int64_t HW, int C, int G) {
-    int R, CVB, NCB, nb;
-    if (B <= 0 || B > 2048 || !gn_onepass_plan(dtype, B, HW, C, G, &R, &CVB, &NCB, &nb)) return 0;
-    return nb;  // workgroups per sample = rows of the `part` scratch ([B][nb][G][2] floats)
-}
-
-int gmd_groupnorm_onepass(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps, const float* gamma,
-                          const float* beta, int silu, float* part, unsigned* sync_counters, gmd_stream_t stream) {
-    GMD_REQUIRE(B > 0 && B <= 2048 && HW > 0 && C > 0 && G > 0, "gmd_groupnorm_onepass: bad shape");
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_groupnorm_onepass: bad dtype %d", dtype);
-    GMD_REQUIRE(X && Y && gamma && beta && part && sync_counters, "gmd_groupnorm_onepass: null pointer");
-    GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y), "gmd_groupnorm_onepass: pointers must be 16-byte aligned");
-    int R, CVB, NCB, nb;
-    if (!gn_onepass_plan(dtype, B, HW, C, G, &R, &CVB, &NCB, &nb)) {
-        gmd_set_error("gmd_groupnorm_onepass: shape B=%d HW=%lld C=%d G=%d does not qualify (use gmd_groupnorm_fused / _split)", B, (long long)HW, C, G);
-        return GMD_ERR_UNSUPPORTED;
-    }
-    const int PY = kThreads / CVB;
-    const int rpt = (R + PY - 1) / PY;  // row slots per thread; the kernel is instantiated for 2 / 4 / 8 / 16 (NCB * slots <= 16)
-    const size_t smem = (size_t)PY * C * 2 * sizeof(float) > (size_t)C * 8 ? (size_t)PY * C * 2 * sizeof(float) : (size_t)C * 8;
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(nb, B);
-#define GMD_GN1(T, NCB_, RPT_) gn_onepass_kernel<T, NCB_, RPT_><<<grid, kThreads, smem, s>>>((const T*)X, (T*)Y, HW, C, G, R, CVB, eps, gamma, beta, silu, part, sync_counters)
-#define GMD_GN1_ROWS(T, NCB_)                                                             \
-    do {                                                                                  \
-        if (rpt <= 2 && NCB_ * 2 <= 16) GMD_GN1(T, NCB_, 2);                              \
-        else if (rpt <= 4 && NCB_ * 4 <= 16) GMD_GN1(T, NCB_, (NCB_ * 4 <= 16 ? 4 : 2));  \
-        else if (rpt <= 8 && NCB_ * 8 <= 16) GMD_GN1(T, NCB_, (NCB_ * 8 <= 16 ? 8 : 2));  \
-        else GMD_GN1(T, NCB_, (NCB_ * 16 <= 16 ? 16 : 2));                                \
-    } while (0)
-    if (dtype == GMD_BF16) {
-        if (NCB == 1) GMD_GN1_ROWS(bf16_t, 1); else if (NCB == 2) GMD_GN1_ROWS(bf16_t, 2); else if (NCB == 4) GMD_GN1_ROWS(bf16_t, 4); else GMD_GN1_ROWS(bf16_t, 8);
-    } else {
-        if (NCB == 1) GMD_GN1_ROWS(float, 1); else if (NCB == 2) GMD_GN1_ROWS(float, 2); else if (NCB == 4) GMD_GN1_ROWS(float, 4); else GMD_GN1_ROWS(float, 8);
-    }
-#undef GMD_GN1_ROWS
-#undef GMD_GN1
-    GMD_CHECK_LAUNCH("gmd_groupnorm_onepass");
     return GMD_OK;
 }
 

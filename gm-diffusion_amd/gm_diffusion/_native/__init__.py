@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
-ABI_VERSION = 5
+ABI_VERSION = 4
 
 GMD_F32, GMD_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -49,8 +49,6 @@ SIGNATURES = {
     "gmd_groupnorm_apply": [P, P, I, I, L, I, P, I, P],
     "gmd_groupnorm_split": [P, P, I, I, L, I, I, F, P, P, P, I, P],
     "gmd_groupnorm_fused": [P, P, I, I, L, I, I, F, P, P, I, P],
-    "gmd_groupnorm_onepass_query": [I, I, L, I, I],
-    "gmd_groupnorm_onepass": [P, P, I, I, L, I, I, F, P, P, I, P, P, P],
     "gmd_layernorm": [P, P, I, L, I, P, P, F, P],
     "gmd_geglu": [P, P, I, L, I, P],
     "gmd_timestep_embedding": [P, P, I, I, I, I, F, P],

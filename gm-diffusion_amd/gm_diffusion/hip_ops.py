@@ -78,20 +78,8 @@ class workspace_scope:
         return False
 
 
-SYNC_WORDS = 4096  # uint32 barrier counters kept behind the split-K scratch: zero at rest, reset by the kernels that use them
-
-
 def new_workspace(device):
-    """Per-stream / per-graph scratch: WORKSPACE_BYTES of split-K slabs (never initialised) followed by SYNC_WORDS zeroed
-    uint32 counters for kernels with an in-launch barrier (gmd_groupnorm_onepass)."""
-    ws = torch.empty(WORKSPACE_BYTES // 4 + SYNC_WORDS, dtype=torch.float32, device=device)
-    ws[WORKSPACE_BYTES // 4:].zero_()
-    return ws
-
-
-def _sync_counters(device):
-    """Address of the current stream's (or the capturing graph's) barrier counters."""
-    return _workspace(device).data_ptr() + WORKSPACE_BYTES
+    return torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
 
 
 def _workspace(device):
@@ -102,7 +90,7 @@ def _workspace(device):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
-        ws = _WS[key] = new_workspace(device)
+        ws = _WS[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return ws
 
 
@@ -281,7 +269,6 @@ def groupnorm_apply(x, B, ss, silu):
 # 4-byte accesses only up to 24 KiB; beyond that the strided re-reads lose to the row-contiguous split kernels.
 GN_FUSED_MAX_SLAB = 24 * 1024
 GN_FUSED_MAX_SLAB_VEC16 = 40 * 1024
-GN_ONEPASS = True  # larger slabs: the single-launch register-resident kernel when the shape qualifies, else the split path
 
 
 def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
@@ -301,18 +288,6 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
         tm, t0 = _timed("groupnorm")
         check(lib().gmd_groupnorm_fused(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
                                         _ptr(_f32(beta, "beta")), int(silu), _stream()), "gmd_groupnorm_fused")
-        if tm:
-            tm.end("groupnorm", 0.0, nbytes, t0)
-        return y
-    nb = lib().gmd_groupnorm_onepass_query(dtype_code(x.dtype), B, HW, C, groups) if (GN_ONEPASS and 2 * B <= SYNC_WORDS) else 0
-    if nb > 0:
-        # one launch, one read + one write of the activation: rows stay in registers across an in-kernel per-sample barrier
-        part = torch.empty(B * nb * groups * 2, dtype=torch.float32, device=x.device)
-        y = torch.empty_like(x)
-        tm, t0 = _timed("groupnorm")
-        check(lib().gmd_groupnorm_onepass(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
-                                          _ptr(_f32(beta, "beta")), int(silu), _ptr(part), _sync_counters(x.device), _stream()),
-              "gmd_groupnorm_onepass")
         if tm:
             tm.end("groupnorm", 0.0, nbytes, t0)
         return y

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 5
+#define GMD_ABI_VERSION 4
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -234,18 +234,6 @@ int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, in
  * 128 KiB: use gmd_groupnorm_stats + gmd_groupnorm_apply then. */
 int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps,
                         const float* gamma, const float* beta, int silu, gmd_stream_t stream);
-/* GroupNorm(+SiLU) in ONE launch for activations whose (sample, group) slab is too large for gmd_groupnorm_fused: each
- * workgroup keeps whole pixel rows in registers between the statistics and the normalisation (one read, one write of the
- * activation; gmd_groupnorm_split reads it twice in two launches) and the workgroups of a sample meet on a device-scope
- * counter in between.  gmd_groupnorm_onepass_query returns the number of workgroups per sample (0 = the shape does not
- * qualify: use _fused / _split); `part` is float32 scratch of B * that * G * 2 values, `sync_counters` 2 * B uint32 that are
- * ZERO at rest (the kernel resets them) and private to one stream -- two launches that may overlap must not share them.
- * Replaces the same torch.nn.GroupNorm calls of diffusers' ResnetBlock2D / Transformer2DModel as the functions above. */
-int gmd_groupnorm_onepass_query(int dtype, int B, int64_t HW, int C, int G);
-int gmd_groupnorm_onepass(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps,
-                          const float* gamma, const float* beta, int silu, float* part, unsigned* sync_counters,
-                          gmd_stream_t stream);
-
 /* LayerNorm over the last dim (C % 8 == 0, C <= 2048) */
 int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C,
                   const float* gamma, const float* beta, float eps, gmd_stream_t stream);

@@ -745,53 +745,3 @@ def test_plan_override_cannot_bypass_geglu_tile_rule():
     finally:
         lib().gmd_gemm_plan_override(0, 0, 0, 0)
     assert rel_err(got.float(), want.float()) < 1e-2
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_groupnorm_onepass_barrier_kernel(dtype):
-    """gmd_groupnorm_onepass (one launch, rows kept in registers across an in-kernel per-sample barrier) on the UNet's large
-    activations: against torch, against the split path, launched repeatedly (the barrier counters must return to zero) and on
-    two streams at once (each stream owns its counters)."""
-    from gm_diffusion._native import lib
-
-    o = ops()
-    code = o.dtype_code(dtype)
-    g = torch.Generator().manual_seed(77)
-    shapes = [(8, 4096, 320), (4, 4096, 640), (8, 1024, 640), (8, 1024, 1280), (4, 1024, 1920), (8, 256, 1280), (4, 256, 2560), (1, 4096, 320), (3, 1000, 320)]
-    took = 0
-    for B, HW, C in shapes:
-        nb = lib().gmd_groupnorm_onepass_query(code, B, HW, C, 32)
-        x = (torch.randn(B, HW, C, generator=g) * 2 + 0.5).to(dtype)
-        ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
-        y = F.silu(F.group_norm(x.float().transpose(1, 2), 32, ga, be, 1e-5)).transpose(1, 2)
-        xd, gd, bd = x.to(DEV), ga.to(DEV), be.to(DEV)
-        o.GN_ONEPASS = True
-        got = [o.groupnorm(xd, B, 32, gd, bd, 1e-5, silu=True) for _ in range(3)]
-        o.GN_ONEPASS = False
-        old = o.groupnorm(xd, B, 32, gd, bd, 1e-5, silu=True)
-        o.GN_ONEPASS = True
-        tol_ = 2e-6 if dtype == torch.float32 else 6e-3
-        assert rel_err(got[0].float(), y) < tol_, (B, HW, C, nb)
-        assert torch.equal(got[0], got[1]) and torch.equal(got[1], got[2]), (B, HW, C)  # deterministic, counters reset
-        assert rel_err(got[0].float(), old.float()) < tol_
-        took += nb > 0
-    assert took >= 6  # the large UNet shapes do take the one-pass kernel
-    assert lib().gmd_groupnorm_onepass_query(code, 4, 262144, 128, 32) == 0  # VAE full resolution: too many workgroups per sample
-    # two streams at once, each with its own counters (the per-stream workspace table)
-    B, HW, C = 8, 4096, 320
-    x1 = (torch.randn(B, HW, C, generator=g)).to(dtype).to(DEV)
-    x2 = (torch.randn(B, HW, C, generator=g) * 3).to(dtype).to(DEV)
-    ga, be = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
-    r1, r2 = o.groupnorm(x1, B, 32, ga, be, 1e-5), o.groupnorm(x2, B, 32, ga, be, 1e-5)
-    torch.cuda.synchronize()
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    outs = []
-    for _ in range(10):
-        with torch.cuda.stream(s1):
-            a = o.groupnorm(x1, B, 32, ga, be, 1e-5)
-        with torch.cuda.stream(s2):
-            b = o.groupnorm(x2, B, 32, ga, be, 1e-5)
-        outs.append((a, b))
-    torch.cuda.synchronize()
-    for a, b in outs:
-        assert torch.equal(a, r1) and torch.equal(b, r2)
