@@ -1009,14 +1009,16 @@ struct Plan {
 // contiguous run of the n-fastest tile order) read the same input rows once per filter tap; walking ALL channels of a tap
 // before the next tap makes the re-read distance rows x Cin x 2 bytes, which for Cin >= 640 at 64x64 (5.2 MB) no longer
 // fits the XCD's 4 MiB L2 (rocprofv3 FETCH_SIZE: 9.1x the algorithmic reads on 8x64x64 640->320,
-// profiles/r01_pmc_conv_attention_current.txt).  Blocks of `cblk` channels bring the distance back under ~2.5 MB.
+// profiles/r01_pmc_conv_attention_current.txt).  Blocks of `cblk` channels bring the distance back under 3 MB
+// (rocprofv3 after: 1.97x, 125.5 -> 118.8 us; profiles/r02_pmc_conv_gemm_traffic.txt).  Shapes whose rows already fit keep
+// the tap-major order (cblk == Cin): at 2.6 MB (32x32, Cin 1280) the blocked order measured slower, not faster.
 int conv_channel_block(int B, int Hin, int Win, int Cin, int Cout, int dtype) {
     if (dtype != GMD_BF16) return Cin;
     const int64_t rows_total = (int64_t)B * Hin * Win;
     const int tiles_n = (Cout + 159) / 160;
     const int64_t rows_resident = (int64_t)(64 / tiles_n > 0 ? 64 / tiles_n : 1) * 128;  // input rows under one XCD's resident tiles
     const int64_t rows = rows_total / 8 < rows_resident ? (rows_total + 7) / 8 : rows_resident;
-    const int64_t budget = (5ll << 20) / 2;
+    const int64_t budget = 3ll << 20;
     if (rows * Cin * 2 <= budget) return Cin;
     int best = 64;
     for (int d = 64; d < Cin; d += 64)

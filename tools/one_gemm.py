@@ -8,6 +8,8 @@ g = torch.Generator().manual_seed(0)
 a = torch.randn(M, K, generator=g).bfloat16().cuda(); w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda(); b = torch.randn(N, generator=g).cuda()
 kw = dict(bias=b) if mode == "bias" else {}
 if mode == "f32": kw = dict(out_dtype=torch.float32)
+if mode == "geglu": kw = dict(bias=b, act=ops.ACT_GEGLU)          # the ff1 projection (N = 8C, output [M, N/2])
+if mode == "res": kw = dict(bias=b, residual=torch.randn(M, N, generator=g).bfloat16().cuda())  # o1 / o2 / pout / ff2
 for _ in range(3): ops.gemm_nt(a, w, **kw)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
