@@ -18,6 +18,7 @@
 #include "gmd_common.h"
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -114,16 +115,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // Fused epilogue for 8 consecutive columns n..n+7 of row m (bf16 activations): alpha, bias, per-group row
 // bias, residual, activation, then a 16-byte store (scalar stores on ragged / unaligned edges).
+template <typename HT>
 __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int m, int n, float (&v)[8]) {
     const bool vec_ok = (p.ldc % 8 == 0) && (p.sC % 8 == 0) && (p.residual == nullptr || (p.ldr % 8 == 0 && p.sR % 8 == 0));
     const int nvalid = p.N - n < 8 ? p.N - n : 8;
     const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
-    const bf16_t* res = p.residual ? (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n : nullptr;
+    const HT* res = p.residual ? (const HT*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n : nullptr;
     float rv[8];
     if (res) {
         if (nvalid == 8 && vec_ok) load_vec(res, rv);
         else
-            for (int j = 0; j < 8; ++j) rv[j] = j < nvalid ? bf16_to_f32(res[j]) : 0.f;
+            for (int j = 0; j < 8; ++j) rv[j] = j < nvalid ? Elem<HT>::ld(res + j) : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -145,14 +147,15 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
             for (int j = 0; j < nvalid; ++j) o[j] = v[j];
         }
     } else {
-        bf16_t* o = (bf16_t*)p.C + coff;
+        HT* o = (HT*)p.C + coff;
         if (nvalid == 8 && vec_ok) store_vec(o, v);
         else
-            for (int j = 0; j < nvalid; ++j) o[j] = f32_to_bf16(v[j]);
+            for (int j = 0; j < nvalid; ++j) Elem<HT>::st(o + j, v[j]);
     }
 }
 
 // split-K: sum the fp32 partial slabs ws[s][m][n] in a fixed order, then the fused epilogue
+template <typename HT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
     const int NC = (p.N + 7) / 8;
     const int64_t total = (int64_t)p.M * NC;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                 for (int j = 0; j < nvalid; ++j) v[j] += src[j];
             }
         }
-        epilogue_store8(p, 0, m, n, v);
+        epilogue_store8<HT>(p, 0, m, n, v);
     }
 }
 
@@ -189,7 +192,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 // by the C/D layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds FOUR CONSECUTIVE output columns n of ONE
 // row m: bias/row-bias/residual/activation are applied in registers and each lane stores 8 bytes (bf16) or 16 bytes
 // (fp32 / split-K partials) -- no LDS round trip, no barrier.  mw/nw: first row/column of this wave's tile.
-template <int TM, int TN>
+template <typename HT, int TM, int TN>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (&acc)[TM][TN], int mw, int nw, int frow, int fq,
                                               int z, int ks) {
     const bool vec_c = (p.ldc % 4 == 0) && (p.sC % 4 == 0);
@@ -231,8 +234,8 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
                         o4[e] = h * (0.5f * g * (1.0f + fast_erf(g * 0.70710678118654752440f)));
                     }
                     const int no = (nw + j * 16) / 2 + fq * 4;  // output column in [0, N/2)
-                    bf16_t* o = (bf16_t*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + no;
-                    *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3]));
+                    HT* o = (HT*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + no;
+                    *reinterpret_cast<uint2*>(o) = make_uint2(Half<HT>::pack2(o4[0], o4[1]), Half<HT>::pack2(o4[2], o4[3]));
                 }
             }
             return;
@@ -258,13 +261,13 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
             }
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             if (p.residual) {
-                const bf16_t* res = (const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n;
+                const HT* res = (const HT*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n;
                 if (nvalid == 4 && vec_r) {
                     const uint2 w = *reinterpret_cast<const uint2*>(res);
-                    rv[0] = __uint_as_float(w.x << 16); rv[1] = __uint_as_float(w.x & 0xffff0000u);
-                    rv[2] = __uint_as_float(w.y << 16); rv[3] = __uint_as_float(w.y & 0xffff0000u);
+                    Half<HT>::unpack2(w.x, rv[0], rv[1]);
+                    Half<HT>::unpack2(w.y, rv[2], rv[3]);
                 } else {
-                    for (int e = 0; e < nvalid; ++e) rv[e] = bf16_to_f32(res[e]);
+                    for (int e = 0; e < nvalid; ++e) rv[e] = Elem<HT>::ld(res + e);
                 }
             }
             if (rb) {
@@ -284,10 +287,10 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
                 else
                     for (int e = 0; e < nvalid; ++e) o[e] = v[e];
             } else {
-                bf16_t* o = (bf16_t*)p.C + coff;
-                if (nvalid == 4 && vec_c) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                HT* o = (HT*)p.C + coff;
+                if (nvalid == 4 && vec_c) *reinterpret_cast<uint2*>(o) = make_uint2(Half<HT>::pack2(v[0], v[1]), Half<HT>::pack2(v[2], v[3]));
                 else
-                    for (int e = 0; e < nvalid; ++e) o[e] = f32_to_bf16(v[e]);
+                    for (int e = 0; e < nvalid; ++e) Elem<HT>::st(o + e, v[e]);
             }
         }
     }
@@ -301,7 +304,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
 // residual (16-byte loads, same shape) and activation are applied on the way out in float32, bit-identical to the
 // register epilogue.  Caller guarantees: block tile fully inside M x N, ldc / ldr / batch strides multiples of 8, and a
 // __syncthreads() between the last LDS read of the K loop and this call.
-template <int TM, int TN>
+template <typename HT, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
                                               int z) {
     static_assert(TM % 2 == 0, "halves of two 16-row tiles");
@@ -335,10 +338,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
             float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.residual) {
-                const uint4 w = *reinterpret_cast<const uint4*>((const bf16_t*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
+                const uint4 w = *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
                 const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { add[2 * e] = __uint_as_float(ww[e] << 16); add[2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) Half<HT>::unpack2(ww[e], add[2 * e], add[2 * e + 1]);
             }
             if (p.rowbias) {
                 const int ro = h * 32 + r;  // row offset inside the wave tile
@@ -354,8 +357,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs
-            bf16_t* o = (bf16_t*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
-            *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            HT* o = (HT*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+            *reinterpret_cast<uint4*>(o) = make_uint4(Half<HT>::pack2(v[0], v[1]), Half<HT>::pack2(v[2], v[3]), Half<HT>::pack2(v[4], v[5]), Half<HT>::pack2(v[6], v[7]));
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -394,7 +397,7 @@ __device__ __forceinline__ void epilogue_rows_slab(const GemmParams& p, const f3
 
 // GEGLU variant of epilogue_rows: h * gelu(g) is formed in registers exactly as in epilogue_regs (value / gate tiles of a
 // pair sit in the same lane), staged, and written as [M, N/2] rows with 16-byte stores.
-template <int TM, int TN>
+template <typename HT, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows_geglu(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw,
                                                     int lane, int z) {
     static_assert(TM == 4 && TN % 2 == 0, "two halves of two 16-row tiles; value/gate tile pairs");
@@ -430,8 +433,8 @@ __device__ __forceinline__ void epilogue_rows_geglu(const GemmParams& p, const f
             if (32 * CH % 64 != 0 && r >= 32) continue;
             const float4 a0 = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 8);
             const float4 a1 = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 8 + 4);
-            bf16_t* o = (bf16_t*)p.C + (int64_t)z * p.sC + (int64_t)(mw + h * 32 + r) * p.ldc + nw / 2 + c * 8;
-            *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(a0.x, a0.y), pack_bf16x2(a0.z, a0.w), pack_bf16x2(a1.x, a1.y), pack_bf16x2(a1.z, a1.w));
+            HT* o = (HT*)p.C + (int64_t)z * p.sC + (int64_t)(mw + h * 32 + r) * p.ldc + nw / 2 + c * 8;
+            *reinterpret_cast<uint4*>(o) = make_uint4(Half<HT>::pack2(a0.x, a0.y), Half<HT>::pack2(a0.z, a0.w), Half<HT>::pack2(a1.x, a1.y), Half<HT>::pack2(a1.z, a1.w));
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -465,7 +468,7 @@ __device__ __forceinline__ unsigned conv_tap_offset(const GemmParams& p, bool va
 
 // PF = register prefetch distance in K steps: the global loads of tile kt+PF are issued before the MFMAs of
 // tile kt and are written to LDS at the end of iteration kt+PF-1, i.e. they have PF whole iterations to land.
-template <bool CONV, int BM, int BN, int PF>
+template <typename HT, bool CONV, int BM, int BN, int PF>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int NA = BM / 32, NW = BN / 32;  // staging slots per thread
     constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave along M / N (wave tile = BM/2 x BN/2)
@@ -575,18 +578,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     auto compute = [&](int cur) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 a[TM], b[TN];
+            uint4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = as_frag(*reinterpret_cast<const uint4*>(smem + cur * kStage + lds_off(wr * (BM / 2) + i * 16 + frow, 4 * s + fq)));
+                a[i] = *reinterpret_cast<const uint4*>(smem + cur * kStage + lds_off(wr * (BM / 2) + i * 16 + frow, 4 * s + fq));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b[j] = as_frag(*reinterpret_cast<const uint4*>(smem + cur * kStage + BM * 128 + lds_off(wc * (BN / 2) + j * 16 + frow, 4 * s + fq)));
+                b[j] = *reinterpret_cast<const uint4*>(smem + cur * kStage + BM * 128 + lds_off(wc * (BN / 2) + j * 16 + frow, 4 * s + fq));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane = (m, 4 n's)
+                    acc[i][j] = Half<HT>::mfma16(b[j], a[i], acc[i][j]);  // D[n][m]: lane = (m, 4 n's)
         }
     };
 
@@ -695,12 +698,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
                          (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
         if (rows_ok) {
             __syncthreads();
-            epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * (32 * (TN * 16 + 4)), m0 + wr * (BM / 2), n0 + wc * (BN / 2),
+            epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * (32 * (TN * 16 + 4)), m0 + wr * (BM / 2), n0 + wc * (BN / 2),
                                   lane, z);
             return;
         }
     }
-    epilogue_regs<TM, TN>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 2), frow, fq, z, ks);
+    epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 2), frow, fq, z, ks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool CONV, int WM, int WN, int TN, int NST>
+template <typename HT, bool CONV, int WM, int WN, int TN, int NST>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void gemm_ring_kernel(const GemmParams p) {
     constexpr int NWAVES = WM * WN, TM = 4;
     constexpr int BM = WM * 64, BN = WN * TN * 16;
@@ -876,15 +879,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
         const unsigned char* sW = sA + BM * 128;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 a[TM], b[TN];
+            uint4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as_frag(*reinterpret_cast<const uint4*>(sA + lds_off(wr * 64 + i * 16 + frow, 4 * s2 + fq)));
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const uint4*>(sA + lds_off(wr * 64 + i * 16 + frow, 4 * s2 + fq));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = as_frag(*reinterpret_cast<const uint4*>(sW + lds_off(wc * (TN * 16) + j * 16 + frow, 4 * s2 + fq)));
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const uint4*>(sW + lds_off(wc * (TN * 16) + j * 16 + frow, 4 * s2 + fq));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = Half<HT>::mfma16(b[j], a[i], acc[i][j]);
         }
     };
 
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
             (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
             __syncthreads();
             constexpr int kStripG = 32 * (TN * 8 + 4);
-            epilogue_rows_geglu<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+            epilogue_rows_geglu<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
             return;
         }
     }
@@ -927,9 +930,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
         __syncthreads();  // every wave is done with the K-loop stages: the strips below overwrite them
         constexpr int kStrip = 32 * (TN * 16 + 4);  // floats per wave
         static_assert((size_t)NWAVES * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
-        epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
     } else {
-        epilogue_regs<TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
     }
 }
 
@@ -1095,86 +1098,110 @@ hipError_t opt_in_lds(const void* fn, int bytes) {
     return e;
 }
 
-template <bool CONV, int BM, int BN, int PF>
+template <typename HT, bool CONV, int BM, int BN, int PF>
 hipError_t launch_bf16(const GemmParams& p, int gz, hipStream_t s) {
     constexpr size_t smem = 2 * (BM + BN) * 128;
     if (smem > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into once per (kernel, device)
-        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel<CONV, BM, BN, PF>), (int)smem);
+        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel<HT, CONV, BM, BN, PF>), (int)smem);
         if (e != hipSuccess) return e;
     }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, gz);
-    gemm_bf16_kernel<CONV, BM, BN, PF><<<grid, 256, smem, s>>>(p);
+    gemm_bf16_kernel<HT, CONV, BM, BN, PF><<<grid, 256, smem, s>>>(p);
     return hipGetLastError();
 }
 
-template <bool CONV, int WM, int WN, int TN, int NST>
+template <typename HT, bool CONV, int WM, int WN, int TN, int NST>
 hipError_t launch_ring(const GemmParams& p, int gz, hipStream_t s) {
     constexpr int BM = WM * 64, BN = WN * TN * 16;
     constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
     if (smem > 64 * 1024) {
-        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_ring_kernel<CONV, WM, WN, TN, NST>), (int)smem);
+        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_ring_kernel<HT, CONV, WM, WN, TN, NST>), (int)smem);
         if (e != hipSuccess) return e;
     }
     dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);  // 1-D tile index, remapped per XCD in the kernel
-    gemm_ring_kernel<CONV, WM, WN, TN, NST><<<grid, WM * WN * 64, smem, s>>>(p);
+    gemm_ring_kernel<HT, CONV, WM, WN, TN, NST><<<grid, WM * WN * 64, smem, s>>>(p);
     return hipGetLastError();
+}
+
+// One 16-bit element type (bf16_t or f16_t): plan, kernel choice, split-K reduction.  float16 instantiates the kernels the
+// heuristic actually picks; the register-staged and deeper-ring tuning variants exist for bfloat16 only (plan overrides).
+template <typename HT, bool CONV>
+int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+    constexpr bool kTune = std::is_same<HT, bf16_t>::value;
+    hipError_t e = hipSuccess;
+    const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
+    p.ksplit = pl.ksplit;
+    p.ws = (float*)ws;
+    const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
+    // the fused GEGLU epilogue pairs value / gate tiles of 16 columns inside a wave: only kernels with an even number of
+    // column tiles per wave implement it (the heuristic picks one; a plan override must not bypass that -- the plain
+    // epilogue would write [M, N] into the [M, N/2] output)
+    if (p.act == GMD_ACT_GEGLU) {
+        const bool ring_odd = pl.pf >= 100 ? (pl.bn == 160 || (pl.bm == 64 && pl.bn == 64)) : (pl.pf == 0 && pl.bm == 128 && pl.bn == 160);
+        if (ring_odd || pl.bn == 160 || pl.ksplit > 1) {
+            gmd_set_error("%s: plan %dx%d pf=%d ksplit=%d has no GEGLU epilogue", name, pl.bm, pl.bn, pl.pf, pl.ksplit);
+            return GMD_ERR_UNSUPPORTED;
+        }
+    }
+    bool done = false;
+    if constexpr (kTune) {
+        done = true;
+        // pf 1xx selects a ring kernel (experiments): 1WS with W = waves-in-M (2|4), S = stages
+        if (pl.pf == 143 && pl.bn == 160) e = launch_ring<HT, CONV, 4, 2, 5, 3>(p, gz, s);
+        else if (pl.pf == 143 && pl.bn == 128) e = launch_ring<HT, CONV, 4, 2, 4, 3>(p, gz, s);
+        else if (pl.pf == 123 && pl.bn == 160) e = launch_ring<HT, CONV, 2, 2, 5, 3>(p, gz, s);
+        else if (pl.pf == 124 && pl.bn == 160) e = launch_ring<HT, CONV, 2, 2, 5, 4>(p, gz, s);
+        else if (pl.pf == 122 && pl.bn == 160) e = launch_ring<HT, CONV, 2, 2, 5, 2>(p, gz, s);
+        else if (pl.pf == 122 && pl.bn == 128) e = launch_ring<HT, CONV, 2, 2, 4, 2>(p, gz, s);
+        else if (pl.pf == 123 && pl.bn == 128) e = launch_ring<HT, CONV, 2, 2, 4, 3>(p, gz, s);
+        else if (pl.pf == 124 && pl.bn == 128) e = launch_ring<HT, CONV, 2, 2, 4, 4>(p, gz, s);
+        else if (pl.pf == 103 && pl.bm == 64 && pl.bn == 64) e = launch_ring<HT, CONV, 1, 4, 1, 3>(p, gz, s);
+        else if (pl.pf == 104 && pl.bm == 64 && pl.bn == 64) e = launch_ring<HT, CONV, 1, 4, 1, 4>(p, gz, s);
+        else if (pl.pf == 103 && pl.bm == 64 && pl.bn == 128) e = launch_ring<HT, CONV, 1, 4, 2, 3>(p, gz, s);
+        else if (pl.pf == 104 && pl.bm == 64 && pl.bn == 128) e = launch_ring<HT, CONV, 1, 4, 2, 4>(p, gz, s);
+        else if (pl.pf >= 100) { gmd_set_error("%s: ring variant %d not instantiated for BN=%d", name, pl.pf, pl.bn); return GMD_ERR_UNSUPPORTED; }
+        else if (pl.pf != 0 && pl.bm == 128 && pl.bn == 160)
+            e = pl.pf == 1 ? launch_bf16<HT, CONV, 128, 160, 1>(p, gz, s) : launch_bf16<HT, CONV, 128, 160, 2>(p, gz, s);
+        else if (pl.pf != 0 && pl.bm == 128 && pl.bn == 128)
+            e = pl.pf == 1 ? launch_bf16<HT, CONV, 128, 128, 1>(p, gz, s) : launch_bf16<HT, CONV, 128, 128, 2>(p, gz, s);
+        else if (pl.pf != 0 && !(pl.bm == 128))
+            e = pl.pf == 1 ? launch_bf16<HT, CONV, 64, 64, 1>(p, gz, s) : launch_bf16<HT, CONV, 64, 64, 2>(p, gz, s);
+        else done = false;
+    } else if (pl.pf != 0) {
+        gmd_set_error("%s: plan override pf=%d is instantiated for bfloat16 only", name, pl.pf);
+        return GMD_ERR_UNSUPPORTED;
+    }
+    if (!done) {
+        // default: two-stage LDS-DMA ring, 4 waves, two workgroups per CU (fastest of all variants measured on MI355X);
+        // 64x64 LDS-DMA tiles for launches that cannot put 256 of the large tiles on the chip
+        if (pl.bm == 128 && pl.bn == 160) e = launch_ring<HT, CONV, 2, 2, 5, 2>(p, gz, s);
+        else if (pl.bm == 128 && pl.bn == 128) e = launch_ring<HT, CONV, 2, 2, 4, 2>(p, gz, s);
+        else if (pl.bm == 64 && pl.bn == 64) e = launch_bf16<HT, CONV, 64, 64, 0>(p, gz, s);
+        else { gmd_set_error("%s: tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
+    }
+    if (e == hipSuccess && pl.ksplit > 1) {
+        const int64_t total = (int64_t)p.M * ((p.N + 7) / 8);
+        int64_t g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        splitk_reduce_kernel<HT><<<(int)g, 256, 0, s>>>(p);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        gmd_set_error("%s: launch failed: %s", name, hipGetErrorString(e));
+        return GMD_ERR_LAUNCH;
+    }
+    return GMD_OK;
 }
 
 template <bool CONV>
 int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
-    hipError_t e = hipSuccess;
-    if (dtype == GMD_BF16) {
-        const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
-        p.ksplit = pl.ksplit;
-        p.ws = (float*)ws;
-        const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
-        // the fused GEGLU epilogue pairs value / gate tiles of 16 columns inside a wave: only kernels with an even number of
-        // column tiles per wave implement it (the heuristic picks one; a plan override must not bypass that -- the plain
-        // epilogue would write [M, N] into the [M, N/2] output)
-        if (p.act == GMD_ACT_GEGLU) {
-            const bool ring_odd = pl.pf >= 100 ? (pl.bn == 160 || (pl.bm == 64 && pl.bn == 64)) : (pl.pf == 0 && pl.bm == 128 && pl.bn == 160);
-            if (ring_odd || pl.bn == 160 || pl.ksplit > 1) {
-                gmd_set_error("%s: plan %dx%d pf=%d ksplit=%d has no GEGLU epilogue", name, pl.bm, pl.bn, pl.pf, pl.ksplit);
-                return GMD_ERR_UNSUPPORTED;
-            }
-        }
-        // pf 1xx selects a ring kernel (experiments): 1WS with W = waves-in-M (2|4), S = stages
-        if (pl.pf == 143 && pl.bn == 160) e = launch_ring<CONV, 4, 2, 5, 3>(p, gz, s);
-        else if (pl.pf == 143 && pl.bn == 128) e = launch_ring<CONV, 4, 2, 4, 3>(p, gz, s);
-        else if (pl.pf == 123 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 3>(p, gz, s);
-        else if (pl.pf == 124 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 4>(p, gz, s);
-        else if (pl.pf == 122 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 2>(p, gz, s);
-        else if (pl.pf == 122 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 2>(p, gz, s);
-        else if (pl.pf == 123 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 3>(p, gz, s);
-        else if (pl.pf == 124 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 4>(p, gz, s);
-        else if (pl.pf == 103 && pl.bm == 64 && pl.bn == 64) e = launch_ring<CONV, 1, 4, 1, 3>(p, gz, s);
-        else if (pl.pf == 104 && pl.bm == 64 && pl.bn == 64) e = launch_ring<CONV, 1, 4, 1, 4>(p, gz, s);
-        else if (pl.pf == 103 && pl.bm == 64 && pl.bn == 128) e = launch_ring<CONV, 1, 4, 2, 3>(p, gz, s);
-        else if (pl.pf == 104 && pl.bm == 64 && pl.bn == 128) e = launch_ring<CONV, 1, 4, 2, 4>(p, gz, s);
-        else if (pl.pf >= 100) { gmd_set_error("%s: ring variant %d not instantiated for BN=%d", name, pl.pf, pl.bn); return GMD_ERR_UNSUPPORTED; }
-        // default: two-stage LDS-DMA ring, 4 waves, two workgroups per CU (fastest of all variants measured on MI355X)
-        else if (pl.pf == 0 && pl.bm == 128 && pl.bn == 160) e = launch_ring<CONV, 2, 2, 5, 2>(p, gz, s);
-        else if (pl.pf == 0 && pl.bm == 128 && pl.bn == 128) e = launch_ring<CONV, 2, 2, 4, 2>(p, gz, s);
-        else if (pl.bm == 128 && pl.bn == 160)
-            e = pl.pf == 0 ? launch_bf16<CONV, 128, 160, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 128, 160, 1>(p, gz, s) : launch_bf16<CONV, 128, 160, 2>(p, gz, s);
-        else if (pl.bm == 128 && pl.bn == 128)
-            e = pl.pf == 0 ? launch_bf16<CONV, 128, 128, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 128, 128, 1>(p, gz, s) : launch_bf16<CONV, 128, 128, 2>(p, gz, s);
-        else
-            e = pl.pf == 0 ? launch_bf16<CONV, 64, 64, 0>(p, gz, s) : pl.pf == 1 ? launch_bf16<CONV, 64, 64, 1>(p, gz, s) : launch_bf16<CONV, 64, 64, 2>(p, gz, s);
-        if (e == hipSuccess && pl.ksplit > 1) {
-            const int64_t total = (int64_t)p.M * ((p.N + 7) / 8);
-            int64_t g = (total + 255) / 256;
-            if (g > 4096) g = 4096;
-            splitk_reduce_kernel<<<(int)g, 256, 0, s>>>(p);
-            e = hipGetLastError();
-        }
-    } else {
-        p.ksplit = 1;
-        p.ws = nullptr;
-        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
-        gemm_f32_kernel<CONV><<<grid, 256, 0, s>>>(p);
-        e = hipGetLastError();
-    }
+    if (dtype == GMD_BF16) return launch_half<bf16_t, CONV>(p, batch, ws, ws_bytes, s, name);
+    if (dtype == GMD_F16) return launch_half<f16_t, CONV>(p, batch, ws, ws_bytes, s, name);
+    p.ksplit = 1;
+    p.ws = nullptr;
+    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
+    gemm_f32_kernel<CONV><<<grid, 256, 0, s>>>(p);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gmd_set_error("%s: launch failed: %s", name, hipGetErrorString(e));
         return GMD_ERR_LAUNCH;

@@ -43,6 +43,13 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// IEEE half: the second 16-bit element type of the MFMA path.  The reference's own half-precision runs are float16
+// (scripts/stage2/experiments/batch_size_sweep.py: `.to(device, dtype=torch.float16)`); with 11 significand bits against
+// bfloat16's 8 the latent drift over a PNDM trajectory is ~8x smaller at the same matrix-core rate.
+typedef _Float16 f16_t;  // a distinct C++ type from bf16_t (= unsigned short), so overloads and Elem<> can tell them apart
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kVec = 4;  // elements per 16 bytes
@@ -55,7 +62,47 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-// 16-byte vector <-> 8 (bf16) or 4 (f32) floats
+template <> struct Elem<f16_t> {
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+};
+
+// Policy of a 16-bit element type on the matrix-core path: fragment type, MFMA forms, pair pack / unpack, the bit pattern
+// of 1.0 and rounding of a float to the element's precision.
+template <typename HT> struct Half;
+template <> struct Half<bf16_t> {
+    static constexpr unsigned kOne = 0x3F80u;
+    __device__ static __forceinline__ unsigned pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    __device__ static __forceinline__ void unpack2(unsigned w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+    __device__ static __forceinline__ float round(float x) { return (float)(__bf16)x; }
+    __device__ static __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Half<f16_t> {
+    static constexpr unsigned kOne = 0x3C00u;
+    __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
+        const f16x2 v = {(_Float16)lo, (_Float16)hi};  // round-to-nearest-even conversions
+        return __builtin_bit_cast(unsigned, v);
+    }
+    __device__ static __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+        const f16x2 v = __builtin_bit_cast(f16x2, w);
+        lo = (float)v[0]; hi = (float)v[1];
+    }
+    __device__ static __forceinline__ float round(float x) { return (float)(_Float16)x; }
+    __device__ static __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+// 16-byte vector <-> 8 (bf16 / f16) or 4 (f32) floats
 __device__ __forceinline__ void load_vec(const bf16_t* p, float (&v)[8]) {
     uint4 r = *reinterpret_cast<const uint4*>(p);
     unsigned w[4] = {r.x, r.y, r.z, r.w};
@@ -71,6 +118,20 @@ __device__ __forceinline__ void store_vec(bf16_t* p, const float (&v)[8]) {
     r.y = pack_bf16x2(v[2], v[3]);
     r.z = pack_bf16x2(v[4], v[5]);
     r.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+__device__ __forceinline__ void load_vec(const f16_t* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Half<f16_t>::unpack2(w[i], v[2 * i], v[2 * i + 1]);
+}
+__device__ __forceinline__ void store_vec(f16_t* p, const float (&v)[8]) {
+    uint4 r;
+    r.x = Half<f16_t>::pack2(v[0], v[1]);
+    r.y = Half<f16_t>::pack2(v[2], v[3]);
+    r.z = Half<f16_t>::pack2(v[4], v[5]);
+    r.w = Half<f16_t>::pack2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = r;
 }
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[4]) {

@@ -39,6 +39,7 @@ extern "C" {
 
 #define GMD_F32 0
 #define GMD_BF16 1
+#define GMD_F16 2  /* IEEE half: same kernels and layouts as GMD_BF16, float16 elements / MFMA forms */
 
 /* epilogue activation for gmd_gemm_nt */
 #define GMD_ACT_NONE 0
