@@ -34,7 +34,7 @@ constexpr int KV = 64;      // keys per tile
 constexpr int VROW = 136;   // bytes per V^T LDS row: 64 keys * 2 B + 8 B pad (conflict-free b64 reads)
 constexpr float kNegBig = -1.0e30f;
 
-template <int D, bool CAUSAL>
+template <typename HT, int D, bool CAUSAL>  // HT: bf16_t or f16_t (storage pointers stay raw 16-bit)
 // d <= 40: four waves per SIMD (128 VGPRs), d <= 64: three (<= 168) -- the softmax VALU of one wave hides under the MFMAs of the others
 __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;         // 16-wide k-steps of Q K^T over d
@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
     // path: subtract the tile's own maximum before exp2.  m is kept bf16-representable so the MFMA subtracts exactly
     // what the rescale assumes.
     constexpr bool kLagged = kRowSumMfma && DK * 16 > D;
-    constexpr float kLagMax = 20.0f;
+    // (P = 2^(score - stabiliser) is converted to the 16-bit type for the second product: 2^20 fits bfloat16, float16 tops
+    // out at 65504, so its window is 2^14)
+    constexpr float kLagMax = std::is_same<HT, f16_t>::value ? 14.0f : 20.0f;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -88,27 +90,33 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
         unsigned char* Vs0 = Ks0 + KV * KROW;
         if (DK * 16 > D) {
             for (int i = tid; i < KV; i += 256)
-                *reinterpret_cast<uint4*>(Ks0 + i * KROW + DC * 16) = make_uint4(kLagged ? 0x3F80u : 0u, 0, 0, 0);  // K[key][D] = 1.0
+                *reinterpret_cast<uint4*>(Ks0 + i * KROW + DC * 16) = make_uint4(kLagged ? Half<HT>::kOne : 0u, 0, 0, 0);  // K[key][D] = 1.0
         }
         for (int i = tid; i < (DT * 32 - D) * (VROW / 8); i += 256) {
             const int row = D + i / (VROW / 8), c = i % (VROW / 8);
-            const unsigned fill = (kRowSumMfma && row == D) ? 0x3F803F80u : 0u;  // bf16 1.0 pairs in the row-sum row
+            const unsigned fill = (kRowSumMfma && row == D) ? (Half<HT>::kOne | (Half<HT>::kOne << 16)) : 0u;  // 1.0 pairs in the row-sum row
             *reinterpret_cast<uint2*>(Vs0 + row * VROW + c * 8) = make_uint2(fill, fill);
         }
     }
 
     // Q fragments (B operand): lane (r, hh) element j = Q[q][16 s + 8 hh + j]
-    bf16x8 qf[DK];
+    uint4 qf[DK];  // raw 16-bit fragments
 #pragma unroll
     for (int s = 0; s < DK; ++s) {
         const int d0 = 16 * s + 8 * hh;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (qvalid && d0 + 8 <= D) v = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * p.ldq + d0);
-        qf[s] = as_frag(v);
         if constexpr (kLagged) {
+            unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)((float)qf[s][j] * p.scale_log2);
+            for (int j = 0; j < 4; ++j) {
+                float lo, hi;
+                Half<HT>::unpack2(w[j], lo, hi);
+                w[j] = Half<HT>::pack2(lo * p.scale_log2, hi * p.scale_log2);
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        qf[s] = v;
     }
 
     f32x16 ot[DT];
@@ -118,11 +126,12 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
         for (int i = 0; i < 16; ++i) ot[t][i] = 0.f;
     float m_run = kLagged ? 0.f : kNegBig, l_run = 0.f;
     [[maybe_unused]] int lag_overflow = 0;
-    [[maybe_unused]] auto set_stabiliser = [&](float m_new) {  // m_new must be bf16-representable
+    [[maybe_unused]] auto set_stabiliser = [&](float m_new) {  // m_new must be representable in the 16-bit type
         constexpr int SP = D / 16, HP = (D % 16) / 8;          // fragment / lane half holding column D of Q
         m_run = m_new;
-        const __bf16 nm = (__bf16)(-m_new);
-        qf[SP < DK ? SP : 0][0] = hh == HP ? nm : qf[SP < DK ? SP : 0][0];
+        const unsigned nm = Half<HT>::pack2(-m_new, 0.0f) & 0xffffu;  // element 0 of the fragment = low half of word 0
+        uint4& f = qf[SP < DK ? SP : 0];
+        f.x = hh == HP ? ((f.x & 0xffff0000u) | nm) : f.x;
     };
 
     // register staging of the NEXT tile: issued before the MFMAs of the current tile, written to the other LDS
@@ -219,8 +228,8 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
             for (int i = 0; i < 16; ++i) st[t][i] = 0.f;
 #pragma unroll
             for (int s = 0; s < DK; ++s) {
-                const bf16x8 kf = as_frag(*reinterpret_cast<const uint4*>(Ks + (32 * t + r) * KROW + (2 * s + hh) * 16));
-                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
+                const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (32 * t + r) * KROW + (2 * s + hh) * 16);
+                st[t] = Half<HT>::mfma32(kf, qf[s], st[t]);
             }
         }
         // mask keys beyond Nk (last tile only; wave-uniform branch)
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[t][i] = __builtin_amdgcn_exp2f(st[t][i]);
-            const float m_new = (float)(__bf16)(m_run + fmaxf(mx, 0.f));
+            const float m_new = Half<HT>::round(m_run + fmaxf(mx, 0.f));
             alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             set_stabiliser(m_new);
         } else {
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
             }
         }
         // P^T -> bf16 B fragments: k-step ks = 2 t + s uses registers 8 s .. 8 s + 7 of tile t
-        bf16x8 pf[4];
+        uint4 pf[4];
         if constexpr (LAG) {
             if (kt + 1 < ntiles) load_kv(k0 + KV);
         }
@@ -292,11 +301,11 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 uint4 w;
-                w.x = pack_bf16x2(st[t][8 * s + 0], st[t][8 * s + 1]);
-                w.y = pack_bf16x2(st[t][8 * s + 2], st[t][8 * s + 3]);
-                w.z = pack_bf16x2(st[t][8 * s + 4], st[t][8 * s + 5]);
-                w.w = pack_bf16x2(st[t][8 * s + 6], st[t][8 * s + 7]);
-                pf[2 * t + s] = as_frag(w);
+                w.x = Half<HT>::pack2(st[t][8 * s + 0], st[t][8 * s + 1]);
+                w.y = Half<HT>::pack2(st[t][8 * s + 2], st[t][8 * s + 3]);
+                w.z = Half<HT>::pack2(st[t][8 * s + 4], st[t][8 * s + 5]);
+                w.w = Half<HT>::pack2(st[t][8 * s + 6], st[t][8 * s + 7]);
+                pf[2 * t + s] = w;
             }
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -307,8 +316,8 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
                 const unsigned char* src = Vs + (32 * dt + r) * VROW + (16 * ks + 4 * hh) * 2;
                 const uint2 lo = *reinterpret_cast<const uint2*>(src);
                 const uint2 hi = *reinterpret_cast<const uint2*>(src + 16);
-                const bf16x8 vf = as_frag(make_uint4(lo.x, lo.y, hi.x, hi.y));
-                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[dt], 0, 0, 0);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                ot[dt] = Half<HT>::mfma32(vf, pf[ks], ot[dt]);
             }
         }
         if constexpr (LAG) {
@@ -338,8 +347,8 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
                 for (int i = 0; i < 16; ++i) s0[i] = 0.f;
 #pragma unroll
                 for (int s = 0; s < DK; ++s) {
-                    const bf16x8 kf = as_frag(*reinterpret_cast<const uint4*>(smem + (32 * t + r) * KROW + (2 * s + hh) * 16));
-                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s0, 0, 0, 0);
+                    const uint4 kf = *reinterpret_cast<const uint4*>(smem + (32 * t + r) * KROW + (2 * s + hh) * 16);
+                    s0 = Half<HT>::mfma32(kf, qf[s], s0);
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
                 }
             }
             mx = half_swap_max(mx);
-            set_stabiliser((float)(__bf16)mx);
+            set_stabiliser(Half<HT>::round(mx));
         }
         for (int kt = 0; kt < ntiles; ++kt) tile(kt, kt & 1, std::true_type{});
         // A score more than 2^kLagMax above the lagged stabiliser could overflow exp2: redo the whole block with the
@@ -393,8 +402,8 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
             const int d0 = 32 * dt + 8 * g + 4 * hh;
             if (d0 < D) {
                 uint2 w;
-                w.x = pack_bf16x2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
-                w.y = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+                w.x = Half<HT>::pack2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
+                w.y = Half<HT>::pack2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(strip + r * SROW + d0 * 2) = w;
             }
         }
@@ -411,12 +420,12 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
     }
 }
 
-template <int D, bool CAUSAL = false>
+template <typename HT, int D, bool CAUSAL = false>
 int launch_attn(const AttnParams& p, int B, int H, hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DT = (D + 31) / 32;
     const size_t smem = 2 * ((size_t)KV * (2 * DK + 1) * 16 + (size_t)DT * 32 * VROW);  // two pipeline stages
     dim3 grid(((p.Nq + 127) / 128) * H * B, 1, 1);  // 1-D: remapped per XCD in the kernel
-    attn_fwd_kernel<D, CAUSAL><<<grid, 256, smem, s>>>(p);
+    attn_fwd_kernel<HT, D, CAUSAL><<<grid, 256, smem, s>>>(p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gmd_set_error("gmd_attention: launch failed: %s", hipGetErrorString(e));
@@ -425,13 +434,34 @@ int launch_attn(const AttnParams& p, int B, int H, hipStream_t s) {
     return GMD_OK;
 }
 
+template <typename HT>
+int dispatch_attn(const AttnParams& p, int B, int H, int D, int Nq, int Nk, int causal, hipStream_t s) {
+    if (causal) {  // the text encoder's mask; instantiated for its head dims (CLIP ViT-L/14: 64)
+        GMD_REQUIRE(Nq == Nk, "gmd_attention: the causal mask needs Nq == Nk");
+        if (D == 64) return launch_attn<HT, 64, true>(p, B, H, s);
+        if (D == 32) return launch_attn<HT, 32, true>(p, B, H, s);
+        gmd_set_error("gmd_attention: causal attention is instantiated for head dims 32 and 64 only (got %d)", D);
+        return GMD_ERR_UNSUPPORTED;
+    }
+    switch (D) {
+        case 32: return launch_attn<HT, 32>(p, B, H, s);
+        case 40: return launch_attn<HT, 40>(p, B, H, s);
+        case 64: return launch_attn<HT, 64>(p, B, H, s);
+        case 80: return launch_attn<HT, 80>(p, B, H, s);
+        case 160: return launch_attn<HT, 160>(p, B, H, s);
+        default:
+            gmd_set_error("gmd_attention: head dim %d not instantiated (supported: 32, 40, 64, 80, 160)", D);
+            return GMD_ERR_UNSUPPORTED;
+    }
+}
+
 }  // namespace
 
 extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void* O, int dtype, int B, int H, int D, int Nq,
                              int Nk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t strideQ, int64_t strideK,
                              int64_t strideVt, int64_t strideO, float scale, int causal, gmd_stream_t stream) {
-    if (dtype != GMD_BF16) {
-        gmd_set_error("gmd_attention: only GMD_BF16 is implemented (the F32 parity path composes gmd_gemm_nt + gmd_softmax_rows)");
+    if (dtype != GMD_BF16 && dtype != GMD_F16) {
+        gmd_set_error("gmd_attention: only GMD_BF16 / GMD_F16 are implemented (the F32 parity path composes gmd_gemm_nt + gmd_softmax_rows)");
         return GMD_ERR_UNSUPPORTED;
     }
     GMD_REQUIRE(B >= 0 && H > 0 && Nq >= 0 && Nk > 0, "gmd_attention: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
@@ -450,21 +480,5 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
     p.sQ = strideQ; p.sK = strideK; p.sVt = strideVt; p.sO = strideO;
     p.scale_log2 = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
-    if (causal) {  // the text encoder's mask; instantiated for its head dims (CLIP ViT-L/14: 64)
-        GMD_REQUIRE(Nq == Nk, "gmd_attention: the causal mask needs Nq == Nk");
-        if (D == 64) return launch_attn<64, true>(p, B, H, s);
-        if (D == 32) return launch_attn<32, true>(p, B, H, s);
-        gmd_set_error("gmd_attention: causal attention is instantiated for head dims 32 and 64 only (got %d)", D);
-        return GMD_ERR_UNSUPPORTED;
-    }
-    switch (D) {
-        case 32: return launch_attn<32>(p, B, H, s);
-        case 40: return launch_attn<40>(p, B, H, s);
-        case 64: return launch_attn<64>(p, B, H, s);
-        case 80: return launch_attn<80>(p, B, H, s);
-        case 160: return launch_attn<160>(p, B, H, s);
-        default:
-            gmd_set_error("gmd_attention: head dim %d not instantiated (supported: 32, 40, 64, 80, 160)", D);
-            return GMD_ERR_UNSUPPORTED;
-    }
+    return dtype == GMD_F16 ? dispatch_attn<f16_t>(p, B, H, D, Nq, Nk, causal, s) : dispatch_attn<bf16_t>(p, B, H, D, Nq, Nk, causal, s);
 }

@@ -95,15 +95,12 @@ int gmd_geglu(const void* X, void* Y, int dtype, int64_t rows, int F, gmd_stream
     if (rows == 0) return GMD_OK;
     GMD_REQUIRE(X && Y && gmd_aligned16(X) && gmd_aligned16(Y), "gmd_geglu: null or unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GMD_BF16) {
-        GMD_REQUIRE(F % 8 == 0, "gmd_geglu: F=%d must be a multiple of 8", F);
-        geglu_kernel<bf16_t><<<grid_for(rows * (F / 8)), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, F);
-    } else if (dtype == GMD_F32) {
-        GMD_REQUIRE(F % 4 == 0, "gmd_geglu: F=%d must be a multiple of 4", F);
-        geglu_kernel<float><<<grid_for(rows * (F / 4)), kThreads, 0, s>>>((const float*)X, (float*)Y, rows, F);
-    } else {
-        GMD_REQUIRE(false, "gmd_geglu: bad dtype %d", dtype);
-    }
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_geglu: bad dtype %d", dtype);
+    GMD_REQUIRE(F % (gmd_is_half(dtype) ? 8 : 4) == 0, "gmd_geglu: F=%d must be a multiple of %d", F, gmd_is_half(dtype) ? 8 : 4);
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        geglu_kernel<T><<<grid_for(rows * (F / Elem<T>::kVec)), kThreads, 0, s>>>((const T*)X, (T*)Y, rows, F);
+    });
     GMD_CHECK_LAUNCH("gmd_geglu");
     return GMD_OK;
 }
@@ -114,12 +111,11 @@ int gmd_timestep_embedding(const float* t_dev, void* out, int dtype, int B, int 
     GMD_REQUIRE(t_dev && out, "gmd_timestep_embedding: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int grid = (B * dim / 2 + 255) / 256;
-    if (dtype == GMD_BF16)
-        temb_kernel<bf16_t><<<grid, 256, 0, s>>>(t_dev, (bf16_t*)out, B, dim, flip_sin_to_cos, freq_shift);
-    else if (dtype == GMD_F32)
-        temb_kernel<float><<<grid, 256, 0, s>>>(t_dev, (float*)out, B, dim, flip_sin_to_cos, freq_shift);
-    else
-        GMD_REQUIRE(false, "gmd_timestep_embedding: bad dtype %d", dtype);
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_timestep_embedding: bad dtype %d", dtype);
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        temb_kernel<T><<<grid, 256, 0, s>>>(t_dev, (T*)out, B, dim, flip_sin_to_cos, freq_shift);
+    });
     GMD_CHECK_LAUNCH("gmd_timestep_embedding");
     return GMD_OK;
 }
@@ -130,32 +126,29 @@ int gmd_concat_channels(const void* A, int Ca, const void* Bm, int Cb, void* out
     GMD_REQUIRE(A && Bm && out, "gmd_concat_channels: null pointer");
     GMD_REQUIRE(gmd_aligned16(A) && gmd_aligned16(Bm) && gmd_aligned16(out), "gmd_concat_channels: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GMD_BF16) {
-        GMD_REQUIRE(Ca % 8 == 0 && Cb % 8 == 0, "gmd_concat_channels: channel counts must be multiples of 8");
-        concat_kernel<bf16_t><<<grid_for(rows * ((Ca + Cb) / 8)), kThreads, 0, s>>>((const bf16_t*)A, Ca, (const bf16_t*)Bm, Cb, (bf16_t*)out, rows);
-    } else if (dtype == GMD_F32) {
-        GMD_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0, "gmd_concat_channels: channel counts must be multiples of 4");
-        concat_kernel<float><<<grid_for(rows * ((Ca + Cb) / 4)), kThreads, 0, s>>>((const float*)A, Ca, (const float*)Bm, Cb, (float*)out, rows);
-    } else {
-        GMD_REQUIRE(false, "gmd_concat_channels: bad dtype %d", dtype);
-    }
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_concat_channels: bad dtype %d", dtype);
+    const int cv = gmd_is_half(dtype) ? 8 : 4;
+    GMD_REQUIRE(Ca % cv == 0 && Cb % cv == 0, "gmd_concat_channels: channel counts must be multiples of %d", cv);
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        concat_kernel<T><<<grid_for(rows * ((Ca + Cb) / cv)), kThreads, 0, s>>>((const T*)A, Ca, (const T*)Bm, Cb, (T*)out, rows);
+    });
     GMD_CHECK_LAUNCH("gmd_concat_channels");
     return GMD_OK;
 }
 
-int gmd_embedding_lookup(const int32_t* ids, const void* table, const void* pos, void* out, int dtype, int64_t rows, int T, int C,
+int gmd_embedding_lookup(const int32_t* ids, const void* table, const void* pos, void* out, int dtype, int64_t rows, int T_, int C,
                          int vocab, gmd_stream_t stream) {
-    GMD_REQUIRE(rows >= 0 && T > 0 && C > 0 && vocab > 0, "gmd_embedding_lookup: bad shape rows=%lld T=%d C=%d vocab=%d", (long long)rows, T, C, vocab);
+    GMD_REQUIRE(rows >= 0 && T_ > 0 && C > 0 && vocab > 0, "gmd_embedding_lookup: bad shape rows=%lld T=%d C=%d vocab=%d", (long long)rows, T_, C, vocab);
     if (rows == 0) return GMD_OK;
     GMD_REQUIRE(ids && table && pos && out, "gmd_embedding_lookup: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for(rows * C);
-    if (dtype == GMD_BF16)
-        embedding_kernel<bf16_t><<<grid, kThreads, 0, s>>>(ids, (const bf16_t*)table, (const bf16_t*)pos, (bf16_t*)out, rows, T, C, vocab);
-    else if (dtype == GMD_F32)
-        embedding_kernel<float><<<grid, kThreads, 0, s>>>(ids, (const float*)table, (const float*)pos, (float*)out, rows, T, C, vocab);
-    else
-        GMD_REQUIRE(false, "gmd_embedding_lookup: bad dtype %d", dtype);
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_embedding_lookup: bad dtype %d", dtype);
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        embedding_kernel<T><<<grid, kThreads, 0, s>>>(ids, (const T*)table, (const T*)pos, (T*)out, rows, T_, C, vocab);
+    });
     GMD_CHECK_LAUNCH("gmd_embedding_lookup");
     return GMD_OK;
 }
@@ -166,16 +159,14 @@ int gmd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, 
     GMD_REQUIRE(in && out, "gmd_cast: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int grid = grid_for(n);
-    if (in_dtype == GMD_F32 && out_dtype == GMD_BF16)
-        cast_kernel<float, bf16_t><<<grid, kThreads, 0, s>>>((const float*)in, (bf16_t*)out, n);
-    else if (in_dtype == GMD_BF16 && out_dtype == GMD_F32)
-        cast_kernel<bf16_t, float><<<grid, kThreads, 0, s>>>((const bf16_t*)in, (float*)out, n);
-    else if (in_dtype == GMD_F32 && out_dtype == GMD_F32)
-        cast_kernel<float, float><<<grid, kThreads, 0, s>>>((const float*)in, (float*)out, n);
-    else if (in_dtype == GMD_BF16 && out_dtype == GMD_BF16)
-        cast_kernel<bf16_t, bf16_t><<<grid, kThreads, 0, s>>>((const bf16_t*)in, (bf16_t*)out, n);
-    else
-        GMD_REQUIRE(false, "gmd_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+    GMD_REQUIRE(gmd_known_dtype(in_dtype) && gmd_known_dtype(out_dtype), "gmd_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+    gmd_for_dtype(in_dtype, [&](auto ti) {
+        using TI = decltype(ti);
+        gmd_for_dtype(out_dtype, [&](auto to) {
+            using TO = decltype(to);
+            cast_kernel<TI, TO><<<grid, kThreads, 0, s>>>((const TI*)in, (TO*)out, n);
+        });
+    });
     GMD_CHECK_LAUNCH("gmd_cast");
     return GMD_OK;
 }

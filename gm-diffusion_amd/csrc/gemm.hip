@@ -1016,7 +1016,7 @@ struct Plan {
 // (rocprofv3 after: 1.97x, 125.5 -> 118.8 us; profiles/r02_pmc_conv_gemm_traffic.txt).  Shapes whose rows already fit keep
 // the tap-major order (cblk == Cin): at 2.6 MB (32x32, Cin 1280) the blocked order measured slower, not faster.
 int conv_channel_block(int B, int Hin, int Win, int Cin, int Cout, int dtype) {
-    if (dtype != GMD_BF16) return Cin;
+    if (dtype == GMD_F32) return Cin;
     const int64_t rows_total = (int64_t)B * Hin * Win;
     const int tiles_n = (Cout + 159) / 160;
     const int64_t rows_resident = (int64_t)(64 / tiles_n > 0 ? 64 / tiles_n : 1) * 128;  // input rows under one XCD's resident tiles
@@ -1223,11 +1223,12 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,
                 const float* rowbias, int rows_per_group, int64_t ldrb, const void* residual, int64_t ldr, int64_t strideR, float alpha,
                 int act, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_gemm_nt: bad dtype %d", dtype);
+    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32, "gmd_gemm_nt: bad dtype %d", dtype);
+    const bool is16 = dtype != GMD_F32;
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
     GMD_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gmd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     if (M == 0 || N == 0 || batch == 0) return GMD_OK;
-    const int kmul = dtype == GMD_BF16 ? 64 : 4, vec = dtype == GMD_BF16 ? 8 : 4;
+    const int kmul = is16 ? 64 : 4, vec = is16 ? 8 : 4;
     GMD_REQUIRE(K % kmul == 0, "gmd_gemm_nt: K=%d must be a multiple of %d", K, kmul);
     GMD_REQUIRE(lda >= K && ldw >= K && (ldc >= N || act == GMD_ACT_GEGLU), "gmd_gemm_nt: leading dimension too small");
     GMD_REQUIRE(lda % vec == 0 && ldw % vec == 0 && strideA % vec == 0 && strideW % vec == 0,
@@ -1239,7 +1240,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     GMD_REQUIRE(residual == nullptr || out_dtype == dtype || dtype == GMD_F32, "gmd_gemm_nt: residual needs out_dtype == dtype");
     GMD_REQUIRE(act == GMD_ACT_NONE || act == GMD_ACT_SILU || act == GMD_ACT_GEGLU || act == GMD_ACT_QUICK_GELU, "gmd_gemm_nt: bad act %d", act);
     if (act == GMD_ACT_GEGLU) {
-        GMD_REQUIRE(dtype == GMD_BF16 && out_dtype == GMD_BF16, "gmd_gemm_nt: GEGLU epilogue is implemented for bf16 only");
+        GMD_REQUIRE(is16 && out_dtype == dtype, "gmd_gemm_nt: GEGLU epilogue is implemented for the 16-bit types only");
         GMD_REQUIRE(N % 32 == 0 && ldc >= N / 2 && ldc % 4 == 0 && strideC % 4 == 0, "gmd_gemm_nt: GEGLU needs N %% 32 == 0 and ldc >= N/2");
         GMD_REQUIRE(!residual && !rowbias, "gmd_gemm_nt: GEGLU epilogue takes no residual / rowbias");
     }
@@ -1249,7 +1250,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = strideA; p.sW = strideW; p.sC = strideC;
     {
         const int64_t ab = ((int64_t)(M - 1) * lda + K) * 2, wb = ((int64_t)(N - 1) * ldw + K) * 2;
-        GMD_REQUIRE(dtype != GMD_BF16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_gemm_nt: operand slab larger than 4 GiB");
+        GMD_REQUIRE(!is16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_gemm_nt: operand slab larger than 4 GiB");
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     }
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.ldrb = ldrb > 0 ? ldrb : N;
@@ -1262,14 +1263,15 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
                 int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_conv3x3: bad dtype %d", dtype);
+    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32, "gmd_conv3x3: bad dtype %d", dtype);
+    const bool is16 = dtype != GMD_F32;
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_conv3x3: out_dtype must be F32 or the input dtype");
     GMD_REQUIRE(B >= 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "gmd_conv3x3: bad shape");
     if (B == 0) return GMD_OK;  // empty batch
     GMD_REQUIRE(stride == 1 || stride == 2, "gmd_conv3x3: stride must be 1 or 2");
     GMD_REQUIRE(!(upsample && stride != 1), "gmd_conv3x3: upsample requires stride 1");
     GMD_REQUIRE(pad_mode == 0 || (pad_mode == 1 && stride == 2 && !upsample), "gmd_conv3x3: pad_mode 1 requires stride 2");
-    const int kmul = dtype == GMD_BF16 ? 64 : 16;
+    const int kmul = is16 ? 64 : 16;
     GMD_REQUIRE(Cin % kmul == 0, "gmd_conv3x3: Cin=%d must be a multiple of %d (pad the channels)", Cin, kmul);
     GMD_REQUIRE(X && Wt && Y && gmd_aligned16(X) && gmd_aligned16(Wt) && gmd_aligned16(Y), "gmd_conv3x3: null or unaligned pointer");
     GMD_REQUIRE(bias == nullptr || gmd_aligned16(bias), "gmd_conv3x3: bias must be 16-byte aligned (it is read with float4 loads)");
@@ -1286,7 +1288,7 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     p.lda = Cin; p.ldw = 9 * (int64_t)Cin; p.ldc = Cout;
     {
         const int64_t ab = (int64_t)B * Hin * Win * Cin * 2, wb = (int64_t)Cout * 9 * Cin * 2;
-        GMD_REQUIRE(dtype != GMD_BF16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_conv3x3: tensor larger than 4 GiB");
+        GMD_REQUIRE(!is16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_conv3x3: tensor larger than 4 GiB");
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     }
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = Hout * Wout; p.ldrb = ldrb > 0 ? ldrb : Cout;

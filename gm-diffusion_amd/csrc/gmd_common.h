@@ -142,6 +142,17 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// host side: dtype codes -> element types
+static inline bool gmd_is_half(int dtype) { return dtype == GMD_BF16 || dtype == GMD_F16; }
+static inline bool gmd_known_dtype(int dtype) { return dtype == GMD_F32 || gmd_is_half(dtype); }
+// run f(T{}) with T = float / bf16_t / f16_t (the caller has validated the code)
+template <typename F>
+static inline void gmd_for_dtype(int dtype, F&& f) {
+    if (dtype == GMD_BF16) f(bf16_t{});
+    else if (dtype == GMD_F16) f(f16_t{});
+    else f(float{});
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // Wave-wide reductions on the data-parallel-primitive (DPP) path: quad permutes, then the two row mirrors, then the four

@@ -245,7 +245,7 @@ int gmd_hdr_tail(const void* sdr_dec, const void* gm_dec, int in_dtype, int in_l
     GMD_REQUIRE(sdr_dec && gm_dec, "gmd_hdr_tail: null input");
     GMD_REQUIRE(B >= 0 && H >= 0 && W >= 0, "gmd_hdr_tail: negative shape");
     GMD_REQUIRE(in_layout >= 0 && in_layout <= 2, "gmd_hdr_tail: in_layout must be 0 (NCHW), 1 (NHWC3) or 2 (NHWC4)");
-    GMD_REQUIRE(in_dtype == GMD_F32 || in_dtype == GMD_BF16, "gmd_hdr_tail: bad dtype %d", in_dtype);
+    GMD_REQUIRE(gmd_known_dtype(in_dtype), "gmd_hdr_tail: bad dtype %d", in_dtype);
     const int64_t HW = (int64_t)H * W;
     if ((int64_t)B * HW == 0) return GMD_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -256,12 +256,12 @@ int gmd_hdr_tail(const void* sdr_dec, const void* gm_dec, int in_dtype, int in_l
     if (vec4)
         hdr_tail_vec4_kernel<<<grid_for((int64_t)B * HW / 4), kThreads, 0, s>>>((const float4*)sdr_dec, (const float4*)gm_dec, (int64_t)B * HW / 4, qmax,
                                                                                 eps, flags, sdr_img, gm_img, sdr_u8, gm_u8, hdr, hdr_file, hdr_u16);
-    else if (in_dtype == GMD_F32)
-        hdr_tail_kernel<float><<<grid, kThreads, 0, s>>>((const float*)sdr_dec, (const float*)gm_dec, in_layout, B, HW, qmax, eps,
-                                                         flags, sdr_img, gm_img, sdr_u8, gm_u8, hdr, hdr_file, hdr_u16);
     else
-        hdr_tail_kernel<bf16_t><<<grid, kThreads, 0, s>>>((const bf16_t*)sdr_dec, (const bf16_t*)gm_dec, in_layout, B, HW, qmax, eps,
-                                                          flags, sdr_img, gm_img, sdr_u8, gm_u8, hdr, hdr_file, hdr_u16);
+        gmd_for_dtype(in_dtype, [&](auto tag) {
+            using T = decltype(tag);
+            hdr_tail_kernel<T><<<grid, kThreads, 0, s>>>((const T*)sdr_dec, (const T*)gm_dec, in_layout, B, HW, qmax, eps, flags, sdr_img, gm_img, sdr_u8,
+                                                         gm_u8, hdr, hdr_file, hdr_u16);
+        });
     GMD_CHECK_LAUNCH("gmd_hdr_tail");
     return GMD_OK;
 }

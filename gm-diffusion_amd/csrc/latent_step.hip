@@ -265,12 +265,11 @@ int gmd_pack_unet_input(const float* src0, int C0, const float* src1, int C1, in
     if ((int64_t)B * HW == 0) return GMD_OK;
     GMD_REQUIRE(src0 && out, "gmd_pack_unet_input: null pointer");
     const int64_t total = (int64_t)B * HW * (CP / 8);
-    if (out_dtype == GMD_F32)
-        pack_kernel<float><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(src0, C0, src1, C1, B, HW, dup, (float*)out, CP);
-    else if (out_dtype == GMD_BF16)
-        pack_kernel<bf16_t><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(src0, C0, src1, C1, B, HW, dup, (bf16_t*)out, CP);
-    else
-        GMD_REQUIRE(false, "gmd_pack_unet_input: bad dtype %d", out_dtype);
+    GMD_REQUIRE(gmd_known_dtype(out_dtype), "gmd_pack_unet_input: bad dtype %d", out_dtype);
+    gmd_for_dtype(out_dtype, [&](auto tag) {
+        using T = decltype(tag);
+        pack_kernel<T><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(src0, C0, src1, C1, B, HW, dup, (T*)out, CP);
+    });
     GMD_CHECK_LAUNCH("gmd_pack_unet_input");
     return GMD_OK;
 }
@@ -280,12 +279,11 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
     if ((int64_t)B * HW == 0) return GMD_OK;
     GMD_REQUIRE(in && out, "gmd_unpack_nchw: null pointer");
     const int64_t total = (int64_t)B * C * HW;
-    if (in_dtype == GMD_F32)
-        unpack_kernel<float><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>((const float*)in, ld, B, C, HW, out);
-    else if (in_dtype == GMD_BF16)
-        unpack_kernel<bf16_t><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)in, ld, B, C, HW, out);
-    else
-        GMD_REQUIRE(false, "gmd_unpack_nchw: bad dtype %d", in_dtype);
+    GMD_REQUIRE(gmd_known_dtype(in_dtype), "gmd_unpack_nchw: bad dtype %d", in_dtype);
+    gmd_for_dtype(in_dtype, [&](auto tag) {
+        using T = decltype(tag);
+        unpack_kernel<T><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>((const T*)in, ld, B, C, HW, out);
+    });
     GMD_CHECK_LAUNCH("gmd_unpack_nchw");
     return GMD_OK;
 }

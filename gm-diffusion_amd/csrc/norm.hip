@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict_
     auto unpack = [](const vec_t& w, float (&v)[EP]) {
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            if (sizeof(T) == 2) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+            if constexpr (sizeof(T) == 2) Half<T>::unpack2(w[k], v[(2 * k) % EP], v[(2 * k + 1) % EP]);
             else v[k] = __uint_as_float(w[k]);
         }
     };
@@ -270,7 +270,10 @@ __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict_
         }
         vec_t o;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) o[k] = sizeof(T) == 2 ? pack_bf16x2(v[(2 * k) % EP], v[(2 * k + 1) % EP]) : __float_as_uint(v[k % EP]);
+        for (int k = 0; k < NW; ++k) {
+            if constexpr (sizeof(T) == 2) o[k] = Half<T>::pack2(v[(2 * k) % EP], v[(2 * k + 1) % EP]);
+            else o[k] = __float_as_uint(v[k % EP]);
+        }
         *reinterpret_cast<vec_t*>(Yg + (int64_t)px * C + j * EP) = o;
         px += dq; j += dr;
         if (j >= vpr) { j -= vpr; ++px; }
@@ -458,8 +461,8 @@ int gmd_groupnorm_stats(const void* X, int dtype, int B, int64_t HW, int C, int 
     GMD_REQUIRE(C % G == 0, "gmd_groupnorm_stats: C=%d not divisible by G=%d", C, G);
     GMD_REQUIRE(X && gamma && beta && workspace && scale_shift, "gmd_groupnorm_stats: null pointer");
     GMD_REQUIRE(gmd_aligned16(X), "gmd_groupnorm_stats: X not 16-byte aligned");
-    const int V = dtype == GMD_BF16 ? 8 : 4;
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_groupnorm_stats: bad dtype %d", dtype);
+    const int V = gmd_is_half(dtype) ? 8 : 4;
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_groupnorm_stats: bad dtype %d", dtype);
     GMD_REQUIRE(C % V == 0, "gmd_groupnorm_stats: C=%d must be a multiple of %d", C, V);
     const int nsplit = gmd_groupnorm_nsplit(HW);
     const int CV = C / V, CVB = CV < kThreads ? CV : kThreads, PY = kThreads / CVB;
@@ -467,10 +470,10 @@ int gmd_groupnorm_stats(const void* X, int dtype, int B, int64_t HW, int C, int 
     GMD_REQUIRE(smem <= 64 * 1024, "gmd_groupnorm_stats: C=%d too large", C);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nsplit, B);
-    if (dtype == GMD_BF16)
-        gn_partial_kernel<bf16_t><<<grid, kThreads, smem, s>>>((const bf16_t*)X, HW, C, G, nsplit, workspace);
-    else
-        gn_partial_kernel<float><<<grid, kThreads, smem, s>>>((const float*)X, HW, C, G, nsplit, workspace);
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        gn_partial_kernel<T><<<grid, kThreads, smem, s>>>((const T*)X, HW, C, G, nsplit, workspace);
+    });
     GMD_CHECK_LAUNCH("gmd_groupnorm_stats(partial)");
     gn_finalize_kernel<<<B, kThreads, 0, s>>>(workspace, nsplit, HW, C, G, eps, gamma, beta, scale_shift);
     GMD_CHECK_LAUNCH("gmd_groupnorm_stats(finalize)");
@@ -482,9 +485,9 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
     GMD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0, "gmd_groupnorm_split: bad shape B=%d HW=%lld C=%d G=%d", B, (long long)HW, C, G);
     GMD_REQUIRE(X && Y && gamma && beta && workspace, "gmd_groupnorm_split: null pointer");
     GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y), "gmd_groupnorm_split: pointers must be 16-byte aligned");
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_groupnorm_split: bad dtype %d", dtype);
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_groupnorm_split: bad dtype %d", dtype);
     GMD_REQUIRE(B <= 65535, "gmd_groupnorm_split: batch too large");
-    const int V = dtype == GMD_BF16 ? 8 : 4;
+    const int V = gmd_is_half(dtype) ? 8 : 4;
     GMD_REQUIRE(C % V == 0, "gmd_groupnorm_split: C=%d must be a multiple of %d", C, V);
     const int nsplit = gmd_groupnorm_nsplit(HW);
     const int CV = C / V, CVB = CV < kThreads ? CV : kThreads, PY = kThreads / CVB;
@@ -495,16 +498,16 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
     int64_t nb = (HW + 127) / 128;
     while (nb * B < 512 && nb < HW) nb *= 2;
     if (nb > HW) nb = HW;
-    if (dtype == GMD_BF16) {
-        gn_partial_kernel<bf16_t><<<dim3(nsplit, B), kThreads, smem, s>>>((const bf16_t*)X, HW, C, G, nsplit, workspace);
-        GMD_CHECK_LAUNCH("gmd_groupnorm_split(partial)");
-        gn_apply_ws_kernel<bf16_t><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const bf16_t*)X, (bf16_t*)Y, HW, C, G, nsplit, eps,
-                                                                                           workspace, gamma, beta, silu);
-    } else {
-        gn_partial_kernel<float><<<dim3(nsplit, B), kThreads, smem, s>>>((const float*)X, HW, C, G, nsplit, workspace);
-        GMD_CHECK_LAUNCH("gmd_groupnorm_split(partial)");
-        gn_apply_ws_kernel<float><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const float*)X, (float*)Y, HW, C, G, nsplit, eps, workspace,
-                                                                                         gamma, beta, silu);
+    bool partial_ok = true;
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        gn_partial_kernel<T><<<dim3(nsplit, B), kThreads, smem, s>>>((const T*)X, HW, C, G, nsplit, workspace);
+        if (hipGetLastError() != hipSuccess) { partial_ok = false; return; }
+        gn_apply_ws_kernel<T><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, nsplit, eps, workspace, gamma, beta, silu);
+    });
+    if (!partial_ok) {
+        gmd_set_error("gmd_groupnorm_split(partial): launch failed");
+        return GMD_ERR_LAUNCH;
     }
     GMD_CHECK_LAUNCH("gmd_groupnorm_split(apply)");
     return GMD_OK;
@@ -516,15 +519,12 @@ int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, in
     GMD_REQUIRE(X && Y && scale_shift, "gmd_groupnorm_apply: null pointer");
     GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y) && gmd_aligned16(scale_shift), "gmd_groupnorm_apply: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GMD_BF16) {
-        GMD_REQUIRE(C % 8 == 0, "gmd_groupnorm_apply: C=%d must be a multiple of 8", C);
-        gn_apply_kernel<bf16_t><<<grid_for((int64_t)B * HW * (C / 8)), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, B, HW, C, scale_shift, silu);
-    } else if (dtype == GMD_F32) {
-        GMD_REQUIRE(C % 4 == 0, "gmd_groupnorm_apply: C=%d must be a multiple of 4", C);
-        gn_apply_kernel<float><<<grid_for((int64_t)B * HW * (C / 4)), kThreads, 0, s>>>((const float*)X, (float*)Y, B, HW, C, scale_shift, silu);
-    } else {
-        GMD_REQUIRE(false, "gmd_groupnorm_apply: bad dtype %d", dtype);
-    }
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_groupnorm_apply: bad dtype %d", dtype);
+    GMD_REQUIRE(C % (gmd_is_half(dtype) ? 8 : 4) == 0, "gmd_groupnorm_apply: C=%d must be a multiple of %d", C, gmd_is_half(dtype) ? 8 : 4);
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        gn_apply_kernel<T><<<grid_for((int64_t)B * HW * (C / Elem<T>::kVec)), kThreads, 0, s>>>((const T*)X, (T*)Y, B, HW, C, scale_shift, silu);
+    });
     GMD_CHECK_LAUNCH("gmd_groupnorm_apply");
     return GMD_OK;
 }
@@ -533,12 +533,12 @@ int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, in
                         const float* beta, int silu, gmd_stream_t stream) {
     GMD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "gmd_groupnorm_fused: bad shape");
     GMD_REQUIRE(X && Y && gamma && beta, "gmd_groupnorm_fused: null pointer");
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F32, "gmd_groupnorm_fused: bad dtype %d", dtype);
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_groupnorm_fused: bad dtype %d", dtype);
     GMD_REQUIRE(B <= 65535, "gmd_groupnorm_fused: batch too large");
-    const int cpg = C / G, epw = dtype == GMD_BF16 ? 2 : 1;
+    const int cpg = C / G, epw = gmd_is_half(dtype) ? 2 : 1;
     GMD_REQUIRE(cpg % epw == 0 && C % epw == 0 && (reinterpret_cast<uintptr_t>(X) & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 3) == 0,
-                "gmd_groupnorm_fused: channels per group must be even for bf16");
-    const int64_t slab_bytes = HW * cpg * (dtype == GMD_BF16 ? 2 : 4);
+                "gmd_groupnorm_fused: channels per group must be even for the 16-bit types");
+    const int64_t slab_bytes = HW * cpg * (gmd_is_half(dtype) ? 2 : 4);
     if (slab_bytes > 128 * 1024 || HW * (int64_t)C >= (1LL << 31)) {
         gmd_set_error("gmd_groupnorm_fused: group slab of %lld bytes is too large for the single-launch kernel (use gmd_groupnorm_stats + _apply)", (long long)slab_bytes);
         return GMD_ERR_UNSUPPORTED;
@@ -546,17 +546,16 @@ int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, in
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(G, B);
     // widest access that divides a group's channel row and keeps every access aligned (row stride C, group offset g*cpg)
-    const int esz = dtype == GMD_BF16 ? 2 : 4;
+    const int esz = gmd_is_half(dtype) ? 2 : 4;
     const auto ok = [&](int vb) {
         return (cpg * esz) % vb == 0 && (C * esz) % vb == 0 && (reinterpret_cast<uintptr_t>(X) % vb) == 0 && (reinterpret_cast<uintptr_t>(Y) % vb) == 0;
     };
     const int vb = ok(16) ? 16 : ok(8) ? 8 : 4;
 #define GMD_GN_FUSED(T, VB) gn_fused_kernel<T, VB><<<grid, kThreads, 0, s>>>((const T*)X, (T*)Y, (int)HW, C, G, eps, gamma, beta, silu)
-    if (dtype == GMD_BF16) {
-        if (vb == 16) GMD_GN_FUSED(bf16_t, 16); else if (vb == 8) GMD_GN_FUSED(bf16_t, 8); else GMD_GN_FUSED(bf16_t, 4);
-    } else {
-        if (vb == 16) GMD_GN_FUSED(float, 16); else if (vb == 8) GMD_GN_FUSED(float, 8); else GMD_GN_FUSED(float, 4);
-    }
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        if (vb == 16) GMD_GN_FUSED(T, 16); else if (vb == 8) GMD_GN_FUSED(T, 8); else GMD_GN_FUSED(T, 4);
+    });
 #undef GMD_GN_FUSED
     GMD_CHECK_LAUNCH("gmd_groupnorm_fused");
     return GMD_OK;
@@ -570,24 +569,28 @@ int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C, const 
     GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y), "gmd_layernorm: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)((rows + 3) / 4);
-    if (dtype == GMD_BF16) {
+    if (gmd_is_half(dtype)) {
         GMD_REQUIRE(C % 8 == 0, "gmd_layernorm: C=%d must be a multiple of 8", C);
         const bool vecp = gmd_aligned16(gamma) && gmd_aligned16(beta);
-#define GMD_LN_PACKED(LPR) layernorm_packed_kernel<bf16_t, LPR, 5><<<(int)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), kThreads, 0, s>>>( \
-    (const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps)
-        // SD-1.5 widths: every lane busy (LPR lanes per row, five 16-byte chunks each)
-        // (measured, tools/bench_graph_ops.py: 32768 x 320 12.8 -> 10.3 us, 8192 x 640 7.9 -> 7.5 us; at C = 1280 the
-        // 32-lane form needs a cross-row shuffle and LOSES to one wave per row, 4.9 -> 5.8 us, so it is not used there)
-        if (vecp && C == 320) GMD_LN_PACKED(8);
-        else if (vecp && C == 640) GMD_LN_PACKED(16);
-#undef GMD_LN_PACKED
-        // narrow rows (one 16-byte chunk per lane) and many of them: four rows per wave keep four loads in flight
-        else if (C <= 512 && rows >= 8192)
-            layernorm_kernel<bf16_t, 1, 4><<<(int)((rows + 15) / 16), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
-        else if (C <= 1024 && rows >= 4096)
-            layernorm_kernel<bf16_t, 2, 2><<<(int)((rows + 7) / 8), kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
-        else
-            layernorm_kernel<bf16_t, 4, 1><<<grid, kThreads, 0, s>>>((const bf16_t*)X, (bf16_t*)Y, rows, C, gamma, beta, eps);
+        gmd_for_dtype(dtype, [&](auto tag) {
+            using T = decltype(tag);
+            if constexpr (sizeof(T) == 2) {
+                // SD-1.5 widths: every lane busy (LPR lanes per row, five 16-byte chunks each; measured, tools/bench_graph_ops.py:
+                // 32768 x 320 12.8 -> 10.3 us, 8192 x 640 7.9 -> 7.5 us; at C = 1280 the 32-lane form needs a cross-row shuffle
+                // and LOSES to one wave per row, 4.9 -> 5.8 us, so it is not used there)
+                if (vecp && C == 320)
+                    layernorm_packed_kernel<T, 8, 5><<<(int)((rows + 31) / 32), kThreads, 0, s>>>((const T*)X, (T*)Y, rows, C, gamma, beta, eps);
+                else if (vecp && C == 640)
+                    layernorm_packed_kernel<T, 16, 5><<<(int)((rows + 15) / 16), kThreads, 0, s>>>((const T*)X, (T*)Y, rows, C, gamma, beta, eps);
+                // narrow rows (one 16-byte chunk per lane) and many of them: four rows per wave keep four loads in flight
+                else if (C <= 512 && rows >= 8192)
+                    layernorm_kernel<T, 1, 4><<<(int)((rows + 15) / 16), kThreads, 0, s>>>((const T*)X, (T*)Y, rows, C, gamma, beta, eps);
+                else if (C <= 1024 && rows >= 4096)
+                    layernorm_kernel<T, 2, 2><<<(int)((rows + 7) / 8), kThreads, 0, s>>>((const T*)X, (T*)Y, rows, C, gamma, beta, eps);
+                else
+                    layernorm_kernel<T, 4, 1><<<grid, kThreads, 0, s>>>((const T*)X, (T*)Y, rows, C, gamma, beta, eps);
+            }
+        });
     } else if (dtype == GMD_F32) {
         GMD_REQUIRE(C % 4 == 0, "gmd_layernorm: C=%d must be a multiple of 4", C);
         layernorm_kernel<float, 8, 1><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, rows, C, gamma, beta, eps);
@@ -608,6 +611,8 @@ int gmd_softmax_rows(const float* S, int64_t lds_, void* P, int out_dtype, int64
     hipStream_t s = (hipStream_t)stream;
     if (out_dtype == GMD_BF16)
         softmax_rows_kernel<bf16_t><<<(int)rows, kThreads, 0, s>>>(S, lds_, (bf16_t*)P, ldp, cols, scale, causal_nq);
+    else if (out_dtype == GMD_F16)
+        softmax_rows_kernel<f16_t><<<(int)rows, kThreads, 0, s>>>(S, lds_, (f16_t*)P, ldp, cols, scale, causal_nq);
     else if (out_dtype == GMD_F32)
         softmax_rows_kernel<float><<<(int)rows, kThreads, 0, s>>>(S, lds_, (float*)P, ldp, cols, scale, causal_nq);
     else

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
 ABI_VERSION = 4
 
-GMD_F32, GMD_BF16 = 0, 1
+GMD_F32, GMD_BF16, GMD_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float

@@ -223,7 +223,7 @@ class AutoencoderKL(_HipModule):
         C, N = x.shape[-1], H * W
         h = ops.groupnorm(x, B, self.config.norm_num_groups, m["gn"][0], m["gn"][1], 1e-6, silu=False)
         qk = ops.gemm_nt(h.view(B * N, C), m["qk"], bias=m["qkb"])  # [B*N, 2C]
-        npad = _pad_to(N, 64 if self._dtype == torch.bfloat16 else 4)
+        npad = _pad_to(N, 64 if ops.is_half(self._dtype) else 4)
         vt = torch.zeros((B, C, npad), dtype=self._dtype, device=x.device) if npad != N else None
         vt = ops.gemm_nt(m["v"], h.view(B, N, C), out=vt, ldc=npad)  # V^T (bias folded into to_out)
         o = composed_attention(qk, 0, 2 * C, qk, C, 2 * C, vt, B, 1, C, N, N, C ** -0.5, self._dtype)
@@ -247,7 +247,7 @@ class AutoencoderKL(_HipModule):
         # batch in slices (16 images at 1024x1024 would need 8.6 GB for [B, 1024*1024, 256] in bf16).
         up = 2 ** (len(c.block_out_channels) - 1)
         widest = max(c.block_out_channels[0], c.block_out_channels[min(1, len(c.block_out_channels) - 1)])
-        per_image = H * up * W * up * widest * (2 if self._dtype == torch.bfloat16 else 4)
+        per_image = H * up * W * up * widest * (2 if ops.is_half(self._dtype) else 4)
         max_b = max(1, self.max_tensor_bytes // per_image)
         if B > max_b:
             parts = [self.decode_nhwc(z[i:i + max_b]) for i in range(0, B, max_b)]

@@ -138,7 +138,7 @@ class CLIPTextModel(_HipModule):
         C, H = c.hidden_size, c.num_attention_heads
         d = C // H
         scale = d ** -0.5
-        if self._dtype == torch.bfloat16:
+        if ops.is_half(self._dtype):
             return ops.attention(qk, qk, vt, H, T, scale, k_col=C, causal=True)
         return composed_attention(qk, 0, 2 * C, qk, C, 2 * C, vt, B, H, d, T, T, scale, self._dtype, causal=True)
 
@@ -161,7 +161,7 @@ class CLIPTextModel(_HipModule):
         C = c.hidden_size
         h = ops.embedding_lookup(input_ids, w["tok"], w["pos"]).view(B * T, C)
         states = [h.view(B, T, C)]
-        mul = 64 if self._dtype == torch.bfloat16 else 4
+        mul = 64 if ops.is_half(self._dtype) else 4
         ldvt = (T + mul - 1) // mul * mul
         for L in w["layers"]:
             x = ops.layernorm(h, *L["ln1"], c.layer_norm_eps)

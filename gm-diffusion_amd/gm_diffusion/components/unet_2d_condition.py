@@ -19,7 +19,8 @@ hand-written HIP kernels of libgmd_hip.so over channels-last activations:
 State-dict keys follow diffusers so a real SD-1.5 checkpoint loads.
 There is no CPU path: ``forward`` raises ``HipExtensionError`` off-device.
 
-dtype policy: weights/activations are ``self.dtype`` (bfloat16 = MFMA path, float32 = parity
+dtype policy: weights/activations are ``self.dtype`` (bfloat16 or float16 = MFMA path -- float16 is what the
+reference's own half-precision scripts use, scripts/stage2/experiments/batch_size_sweep.py -- float32 = parity
 path); the input latents are float32 NCHW and are cast while being packed; the output eps is
 float32 NCHW taken from the fp32 accumulators of ``conv_out`` (never rounded to bf16).
 """
@@ -89,8 +90,6 @@ class _HipModule(ConfigMixin):
             elif a is not None:
                 device = a
         if dtype is not None:
-            if dtype == torch.float16:
-                raise HipExtensionError("float16 is not implemented in the MI355X build; use bfloat16 or float32")
             self._dtype = dtype
         if device is not None:
             self._device = torch.device(device)
@@ -119,7 +118,7 @@ class _HipModule(ConfigMixin):
 
     # -- layout helpers --------------------------------------------------------------------------
     def _kmul(self):
-        return 64 if self._dtype == torch.bfloat16 else 16
+        return 64 if ops.is_half(self._dtype) else 16
 
     def _act(self, t):
         return t.to(self._device, self._dtype).contiguous()
@@ -149,7 +148,7 @@ def composed_attention(q, q_col, ldq, k, k_col, ldk, vt, B, H, d, nq, nk, scale,
     q/k: buffers with rows of ldq/ldk elements, head h at columns q_col + h*d; vt: [B, H*d, ldvt] with
     zero-filled columns >= nk.  Returns [B, nq, H*d]."""
     es = q.element_size()
-    mul = 64 if dtype == torch.bfloat16 else 4
+    mul = 64 if ops.is_half(dtype) else 4
     nkp = _pad_to(nk, mul)
     ldvt = vt.shape[2]
     if ldvt < nkp:
@@ -382,7 +381,7 @@ class UNet2DConditionModel(_HipModule):
             t["v2"] = self._lin(f"{b}.attn2.to_v", False)[0]
             t["o2"] = self._lin(f"{b}.attn2.to_out.0")
             t["ff1"] = self._lin(f"{b}.ff.net.0.proj")
-            if self._dtype == torch.bfloat16:
+            if ops.is_half(self._dtype):
                 # fused GEGLU epilogue: interleave value / gate rows in groups of 16 so both land in the same MFMA lane
                 wf, bf = self._raw[f"{b}.ff.net.0.proj.weight"], self._raw[f"{b}.ff.net.0.proj.bias"]
                 half = wf.shape[0] // 2
@@ -440,7 +439,7 @@ class UNet2DConditionModel(_HipModule):
         d = C // heads
         scale = d ** -0.5
         qk = ops.gemm_nt(n1, t["qk1"]).view(B, N, 2 * C)
-        if self._dtype == torch.bfloat16:
+        if ops.is_half(self._dtype):
             vt = ops.gemm_nt(t["v1"], n1.view(B, N, C), ldc=_pad_to(N, 8))  # V^T [B, C, N]
             return ops.attention(qk, qk, vt, heads, N, scale, k_col=C)
         npad = _pad_to(N, 4)
@@ -466,7 +465,7 @@ class UNet2DConditionModel(_HipModule):
         if self._capturing:
             raise HipExtensionError("cross-attention K/V must be prepared (update_context) before graph capture")
         C = t["k2"].shape[0]
-        lpad = _pad_to(L, 8 if self._dtype == torch.bfloat16 else 4)
+        lpad = _pad_to(L, 8 if ops.is_half(self._dtype) else 4)
         if ent is None:
             ent = dict(kc=torch.empty((B, L, C), dtype=self._dtype, device=ehs.device),
                        vt=torch.zeros((B, C, lpad), dtype=self._dtype, device=ehs.device))
@@ -513,14 +512,14 @@ class UNet2DConditionModel(_HipModule):
             B *= 2
         kc, vtc = self._cross_kv(t, ehs)
         L = ehs.shape[1]
-        if self._dtype == torch.bfloat16:
+        if ops.is_half(self._dtype):
             o = ops.attention(q, kc, vtc, heads, L, d ** -0.5)
         else:
             o = composed_attention(q, 0, C, kc, 0, C, vtc, B, heads, d, N, L, d ** -0.5, self._dtype)
         h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h)
         # GEGLU feed-forward
         n3 = ops.layernorm(h, *t["norm3"])
-        if self._dtype == torch.bfloat16:
+        if ops.is_half(self._dtype):
             f = ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1], act=ops.ACT_GEGLU)  # h * gelu(g) formed in the GEMM epilogue
         else:
             f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
@@ -647,7 +646,7 @@ class UNet2DConditionModel(_HipModule):
         ehs = ehs.contiguous()
         if ehs.dtype == self._dtype:
             return ehs
-        if ehs.dtype not in (torch.float32, torch.bfloat16):
+        if ehs.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             ehs = ehs.float()
         return ops.cast(ehs, self._dtype)
 

@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 
 from . import profiling
-from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F32, HipExtensionError, check, lib
+from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F16, GMD_F32, HipExtensionError, check, lib
 
 __all__ = [
     "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
@@ -30,7 +30,17 @@ def dtype_code(dt):
         return GMD_F32
     if dt == torch.bfloat16:
         return GMD_BF16
-    raise HipExtensionError(f"unsupported dtype {dt}: the HIP kernels take float32 or bfloat16")
+    if dt == torch.float16:
+        return GMD_F16
+    raise HipExtensionError(f"unsupported dtype {dt}: the HIP kernels take float32, bfloat16 or float16")
+
+
+HALF_DTYPES = (torch.bfloat16, torch.float16)
+
+
+def is_half(dt):
+    """The two 16-bit element types of the matrix-core path (same kernels, layouts and launch plans)."""
+    return dt in HALF_DTYPES
 
 
 def _dev(*ts):
@@ -277,7 +287,7 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
     _dev(x, gamma, beta)
     C = x.shape[-1]
     HW = x.numel() // (B * C)
-    epw = 2 if x.dtype == torch.bfloat16 else 1
+    epw = 2 if is_half(x.dtype) else 1
     cpg = C // groups
     vec16 = (cpg * x.element_size()) % 16 == 0 and (C * x.element_size()) % 16 == 0
     # algorithmic HBM bytes of a GroupNorm: the activation is read once and written once (the statistics pass of the split

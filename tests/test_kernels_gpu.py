@@ -28,8 +28,11 @@ def max_err(a, b):
     return float((a.double().cpu() - b.double().cpu()).abs().max())
 
 
+HALF = (torch.bfloat16, torch.float16)
+
+
 def tol(dtype):
-    return 2e-5 if dtype == torch.float32 else 1.5e-2
+    return 2e-5 if dtype == torch.float32 else (1.5e-2 if dtype == torch.bfloat16 else 2e-3)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -61,7 +64,7 @@ def test_hdr_ops_against_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_hdr_tail_fused_vs_oracle(layout, dtype):
     from oracle import hdr_ops as H
 
@@ -206,12 +209,12 @@ def test_cfg_rescale_matches_torch():
     assert rel_err(eps, ref) < 1e-6
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_pack_unpack(dtype):
     o = ops()
     g = torch.Generator().manual_seed(1)
     a, b = torch.randn(2, 4, 6, 10, generator=g), torch.randn(2, 4, 6, 10, generator=g)
-    cp = 64 if dtype == torch.bfloat16 else 16
+    cp = 64 if dtype in HALF else 16
     out = o.pack_unet_input(a.to(DEV), b.to(DEV), 2, cp, dtype).cpu().float()
     ref = torch.cat([a, b], 1).permute(0, 2, 3, 1).reshape(2, 60, 8).to(dtype).float()
     assert out.shape == (4, 60, cp)
@@ -225,7 +228,7 @@ def test_pack_unpack(dtype):
 # ---------------------------------------------------------------------------------------------
 # normalisation / elementwise
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,HW,C,G", [(2, 64, 320, 32), (1, 4096, 320, 32), (2, 256, 1280, 32), (1, 64, 2560, 32),
                                       (2, 100, 128, 32), (1, 16, 960, 32), (3, 37, 64, 8), (1, 4096, 960, 32), (2, 1024, 1920, 32), (1, 65536, 128, 32)])
 def test_groupnorm(dtype, B, HW, C, G):
@@ -244,7 +247,7 @@ def test_groupnorm(dtype, B, HW, C, G):
         assert rel_err(got2.float(), ref) < (2e-6 if dtype == torch.float32 else 6e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows,C", [(5, 320), (130, 640), (64, 1280), (3, 64), (9, 2048)])
 def test_layernorm(dtype, rows, C):
     o = ops()
@@ -256,7 +259,7 @@ def test_layernorm(dtype, rows, C):
     assert rel_err(got.float(), ref) < (2e-6 if dtype == torch.float32 else 6e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_geglu_concat_cast_temb_softmax(dtype):
     o = ops()
     g = torch.Generator().manual_seed(8)
@@ -285,7 +288,7 @@ def test_geglu_concat_cast_temb_softmax(dtype):
 # ---------------------------------------------------------------------------------------------
 # GEMM / conv
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 320), (8, 1280, 1280), (616, 320, 768), (4096, 320, 320),
                                    (2048, 2560, 320), (33, 4, 128), (70, 1000, 64), (1024, 1280, 5120)])
 def test_gemm_nt(dtype, M, N, K):
@@ -309,7 +312,7 @@ def test_gemm_nt(dtype, M, N, K):
     assert rel_err(got.float(), ref + rb.double().repeat_interleave(rpg, 0)[:M]) < tol(dtype), "rowbias"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_batched_and_swapped(dtype):
     o = ops()
     g = torch.Generator().manual_seed(9)
@@ -326,7 +329,7 @@ def test_gemm_batched_and_swapped(dtype):
     assert rel_err(y.float(), ref2) < tol(dtype)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [
     (2, 8, 8, 64, 64, "s1"), (1, 16, 12, 128, 320, "s1"), (2, 8, 8, 64, 128, "s2"), (1, 9, 7, 64, 64, "s2"),
     (2, 4, 6, 128, 64, "up"), (1, 8, 8, 64, 64, "pad1"), (1, 7, 9, 64, 64, "pad1"), (1, 64, 64, 320, 320, "s1"),
