@@ -58,7 +58,8 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0, help="total prompts over all GPUs (overrides --batch; must divide by the GPU count)")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--inference-steps", type=int, default=50)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="bf16 = BASELINE.json's metric; f16 = the reference's own half type, same kernels (side line); f32 = the parity path")
     ap.add_argument("--unet", default="sd15", choices=["sd15", "tiny"], help="tiny = structural smoke config (not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scheduler", default="pndm", choices=["pndm", "dpm++", "ddpm"],
@@ -171,7 +172,7 @@ def main():
     from gm_diffusion.components import AutoencoderKL, DDPMScheduler, DPMSolverMultistepScheduler, PNDMScheduler, UNet2DConditionModel
     from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
 
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     tiny = a.unet == "tiny"
     ucfg = dict(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, attention_head_dim=2, norm_num_groups=8) if tiny else {}
     vcfg = dict(block_out_channels=(64, 64, 128, 128), norm_num_groups=8) if tiny else {}
@@ -270,7 +271,7 @@ def main():
     # bf16 drift against the float32 HIP path on a SHORT fixed run (1 prompt, `--drift-steps` PNDM steps): the parity gate
     # (latent RMS <= 1e-3 vs the oracle) is met by the float32 path; this is what the benchmarked precision gives up
     drift = None
-    if rank == 0 and a.dtype == "bf16" and not a.no_drift and not tiny:
+    if rank == 0 and a.dtype in ("bf16", "f16") and not a.no_drift and not tiny:
         try:
             f_unet = UNet2DConditionModel(in_channels=4, **ucfg).load_state_dict(unet.state_dict()).to(dev, torch.float32)
             f_gm = UNet2DConditionModel(in_channels=8, **ucfg).load_state_dict(gm_unet.state_dict()).to(dev, torch.float32)
@@ -281,7 +282,7 @@ def main():
             rms = lambda x, y: float(((x.double() - y.double()) ** 2).mean().sqrt().item())
             drift = {"sdr": round(rms(s_b, s_f), 6), "gm": round(rms(g_b, g_f), 6), "latent_rms": round(float(s_f.double().pow(2).mean().sqrt().item()), 4),
                      "pndm_steps": a.drift_steps, "prompts": 1, "resolution": a.res,
-                     "note": "RMS difference of the final latents, bf16 path vs the float32 HIP path (same weights, seed, embeddings); "
+                     "note": f"RMS difference of the final latents, {a.dtype} path vs the float32 HIP path (same weights, seed, embeddings); "
                              "north-star gate 1e-3 is met by the float32 path against the oracle (tests/test_pipeline_gpu.py)"}
             del f_pipe, f_unet, f_gm
             torch.cuda.empty_cache()
@@ -293,7 +294,7 @@ def main():
         kernels = {}
         if timer is not None:
             full = timer.summary()
-            mfma_peak = BF16_DENSE_PEAK_TFLOPS if a.dtype == "bf16" else F32_VECTOR_PEAK_TFLOPS
+            mfma_peak = BF16_DENSE_PEAK_TFLOPS if a.dtype in ("bf16", "f16") else F32_VECTOR_PEAK_TFLOPS  # f16 MFMA = bf16 rate
             all_ms = sum(v["ms"] for v in full.values())
             for k, v in full.items():
                 e = {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_us": round(v["avg_us"], 2), "share": round(v["ms"] / all_ms, 3)}
