@@ -271,7 +271,11 @@ class DDPMScheduler(_SchedulerBase):
             variance = cur_b
         return variance
 
-    def _device_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0, generator):
+    def draws_noise(self, timestep):
+        """True when ``step`` at this timestep consumes the generator (every step but t == 0)."""
+        return int(timestep) > 0
+
+    def _device_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0, generator, noise=None):
         """One HIP kernel pass (gmd_ddpm_step): CFG combine (+rescale), pipeline x0, clipped x0 prediction, posterior mean
         and the variance noise.  The noise is drawn HERE with ``randn_tensor`` exactly where ``step`` draws it, so the
         generator the dual pipeline shares between its two schedulers (stable_diffusion_dual_unet.py:1015, 1077, 1093) is
@@ -287,7 +291,8 @@ class DDPMScheduler(_SchedulerBase):
         xt_coeff = cur_a ** 0.5 * b_p / b_t
         noise, scale = None, 0.0
         if t > 0:
-            noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=torch.float32)
+            if noise is None:  # (the pipelines pre-draw a CPU generator's noise for all steps, in call order: see fused_step)
+                noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=torch.float32)
             v = self._get_variance(t)
             scale = (v if self.config.variance_type == "fixed_small_log" else v ** 0.5).item()
         ratio = ops.cfg_std_ratio(eps_in, guidance_scale) if (do_cfg and guidance_rescale > 0.0) else None
@@ -297,14 +302,16 @@ class DDPMScheduler(_SchedulerBase):
                              do_cfg, guidance_scale, noise=noise, ratio=ratio, guidance_rescale=guidance_rescale,
                              clip_range=self.config.clip_sample_range if self.config.clip_sample else None, want_x0=want_x0)
 
-    def fused_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale=0.0, want_x0=False, generator=None):
+    def fused_step(self, eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale=0.0, want_x0=False, generator=None, noise=None):
         """Same contract as ``PNDMScheduler.fused_step`` plus the generator (device float32 tensors only).
-        Returns (prev_sample, x0 | None)."""
-        return self._device_step(eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0, generator)
+        ``noise``: this step's variance noise already drawn from ``generator`` by the caller (a CPU generator forces a
+        synchronous host draw + copy per step; the pipelines draw all steps up front, in the order the steps consume
+        them, so the host keeps running ahead of the GPU).  Returns (prev_sample, x0 | None)."""
+        return self._device_step(eps_in, timestep, sample, do_cfg, guidance_scale, guidance_rescale, want_x0, generator, noise)
 
-    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, noise=None):
         if model_output.is_cuda and model_output.dtype == torch.float32 and sample.dtype == torch.float32:
-            prev, _ = self._device_step(model_output, timestep, sample, False, 1.0, 0.0, False, generator)
+            prev, _ = self._device_step(model_output, timestep, sample, False, 1.0, 0.0, False, generator, noise)
             return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)
         return self._host_step(model_output, timestep, sample, generator, return_dict)
 

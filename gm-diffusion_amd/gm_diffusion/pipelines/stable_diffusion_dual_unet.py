@@ -141,6 +141,7 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
             if self._graphs_ok():
                 g_sdr = self.unet.graphed_forward(nb_sdr, h, w, ctx, cfg_shared=shared)
                 g_gm = self.gm_unet.graphed_forward(latents.shape[0], h, w, gm_ctx)
+            pre = self._predraw_step_noise([self.scheduler, self.gm_scheduler], ts_host, latents.shape, generator, latents.device)
             gm_stream.wait_stream(sdr_stream)
             if gm_stream is not sdr_stream:
                 # allocated on the caller's stream, consumed (and released) by step 0 on the GM stream: without this the
@@ -158,7 +159,8 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                     pre_step = latents
                     latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, ts_host[i], pre_step, do_cfg, self.guidance_scale,
                                                                    self.guidance_rescale if do_cfg else 0.0, want_x0=True,
-                                                                   **self._fused_step_kwargs(extra_step_kwargs))
+                                                                   **self._fused_step_kwargs(extra_step_kwargs),
+                                                                   **({"noise": pre[0][i]} if pre else {}))
                     with torch.cuda.stream(gm_stream):
                         gm_stream.wait_stream(sdr_stream)  # x0_i is ready
                         x0_latent.record_stream(gm_stream)
@@ -166,7 +168,8 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                         self.gm_unet.set_timestep_from(ts_dev, i)
                         gm_noise_pred = g_gm.replay() if g_gm else self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
                         gm_latents = self.gm_scheduler.step(gm_noise_pred, ts_host[i], gm_latents,
-                                                            **self._fused_step_kwargs(extra_step_kwargs), return_dict=False)[0]
+                                                            **self._fused_step_kwargs(extra_step_kwargs),
+                                                            **({"noise": pre[1][i]} if pre else {}), return_dict=False)[0]
                 else:
                     latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
                     latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)

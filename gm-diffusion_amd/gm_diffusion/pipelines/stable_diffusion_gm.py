@@ -320,6 +320,31 @@ class _GMPipelineBase(DiffusionPipeline):
                 and isinstance(unet, UNet2DConditionModel))
 
     @staticmethod
+    def _predraw_step_noise(schedulers, ts_host, shape, generator, device):
+        """Stochastic schedulers on the fused path with a CPU generator: draw the variance noise of EVERY step now, in exactly
+        the order the loop would consume the generator (per iteration: the schedulers in the order given -- SDR before GM,
+        stable_diffusion_dual_unet.py:1077, 1093), and move it to the device in one asynchronous copy.  A draw inside the
+        loop is a host-side randn + synchronous copy per step, which stops the host from running ahead of the GPU
+        (bench.py --scheduler ddpm: 3.67 -> see DESIGN.md).  Returns one list of per-step tensors (or None) per scheduler,
+        or None when there is nothing to pre-draw (deterministic scheduler, device generator, global RNG)."""
+        from ..components.schedulers import DDPMScheduler
+
+        if generator is None or not all(isinstance(s_, DDPMScheduler) for s_ in schedulers):
+            return None
+        gens = generator if isinstance(generator, list) else [generator]
+        if any(g_.device.type != "cpu" for g_ in gens):
+            return None
+        slots = [(i, k) for i, t in enumerate(ts_host) for k, s_ in enumerate(schedulers) if s_.draws_noise(t)]
+        if not slots:
+            return None
+        host = torch.stack([randn_tensor(shape, generator=generator, device="cpu", dtype=torch.float32) for _ in slots])
+        dev = host.pin_memory().to(device, non_blocking=True) if host.numel() else host.to(device)
+        out = [[None] * len(ts_host) for _ in schedulers]
+        for n, (i, k) in enumerate(slots):
+            out[k][i] = dev[n]
+        return out
+
+    @staticmethod
     def _fused_step_kwargs(extra_step_kwargs):
         """What ``scheduler.fused_step`` takes of the reference's ``extra_step_kwargs``: the generator (stochastic
         schedulers draw their noise from it in call order, stable_diffusion_dual_unet.py:1077, 1093)."""
@@ -426,6 +451,7 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
             hw = latents.shape[-2:]
             shared = self._cfg_shared(self.unet, do_cfg)
             nb = (2 if do_cfg else 1) * latents.shape[0]
+            pre = self._predraw_step_noise([self.scheduler], ts_host, latents.shape, generator, latents.device)
             graph = self.unet.graphed_forward(nb, hw[0], hw[1], ctx, cfg_shared=shared) if self._graphs_ok() else None
 
         with self.progress_bar(total=num_inference_steps) as progress_bar:
@@ -439,7 +465,8 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
                     noise_pred = graph.replay() if graph else self.unet.forward_packed(x, nb, hw[0], hw[1], ctx, cfg_shared=shared)
                     latents, _ = self.scheduler.fused_step(noise_pred, ts_host[i], latents, do_cfg, self.guidance_scale,
                                                            self.guidance_rescale if do_cfg else 0.0,
-                                                           **self._fused_step_kwargs(extra_step_kwargs))
+                                                           **self._fused_step_kwargs(extra_step_kwargs),
+                                                           **({"noise": pre[0][i]} if pre else {}))
                 else:
                     cat_latents = torch.cat([sdr_latent, latents], dim=1)
                     latent_model_input = torch.cat([cat_latents] * 2) if do_cfg else cat_latents
