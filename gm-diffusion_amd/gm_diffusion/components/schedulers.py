@@ -289,7 +289,7 @@ class DDPMScheduler(_SchedulerBase):
         cur_b = 1 - cur_a
         x0_coeff = (a_p ** 0.5 * cur_b) / b_t
         xt_coeff = cur_a ** 0.5 * b_p / b_t
-        noise, scale = None, 0.0
+        scale = 0.0  # (noise: the caller's pre-drawn tensor, or drawn below)
         if t > 0:
             if noise is None:  # (the pipelines pre-draw a CPU generator's noise for all steps, in call order: see fused_step)
                 noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=torch.float32)
