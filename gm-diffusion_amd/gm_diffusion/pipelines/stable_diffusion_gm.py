@@ -325,7 +325,7 @@ class _GMPipelineBase(DiffusionPipeline):
         the order the loop would consume the generator (per iteration: the schedulers in the order given -- SDR before GM,
         stable_diffusion_dual_unet.py:1077, 1093), and move it to the device in one asynchronous copy.  A draw inside the
         loop is a host-side randn + synchronous copy per step, which stops the host from running ahead of the GPU
-        (bench.py --scheduler ddpm: 3.67 -> see DESIGN.md).  Returns one list of per-step tensors (or None) per scheduler,
+        (bench.py --scheduler ddpm: 3.67 -> 4.59 images/s).  Returns one list of per-step tensors (or None) per scheduler,
         or None when there is nothing to pre-draw (deterministic scheduler, device generator, global RNG)."""
         from ..components.schedulers import DDPMScheduler
 
