@@ -18,7 +18,7 @@
  *   - return value: GMD_OK or an error code; gmd_last_error() returns a thread-local
  *     message for the last failing call;
  *   - activations are channels-last: [B, H*W, C] ("NHWC"); `dtype` selects the
- *     activation/weight element type (GMD_BF16 = MFMA path, GMD_F32 = parity path);
+ *     activation/weight element type (GMD_BF16 / GMD_F16 = MFMA path, GMD_F32 = parity path);
  *     biases, norm affine parameters and statistics are always float32.
  */
 #ifndef GMD_HIP_H
