@@ -46,7 +46,6 @@ struct GemmParams {
     // taps of a block before the next block.  cblk == Cin is the plain tap-major order.  A smaller block keeps the rows an
     // XCD re-reads for the next tap inside its 4 MiB L2 (see gmd_conv3x3).
     int cblk;
-    int stagger;  // ring kernel: s_sleep units (64 cycles) by which every second resident workgroup of a CU starts late
 };
 
 // Row-invariant part of the A address of one staging slot.
@@ -912,13 +911,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
         }
     };
 
-    // Two workgroups share a CU (one wave each per SIMD) and run the same loop with the same period: started together they
-    // tend to reach their MFMA clusters, LDS bursts and barriers in lockstep.  The workgroups of the second dispatch round
-    // (ids 256..511 of each 512) start half a K step late, so one wave's MFMA cluster faces the other's DMA issue / LDS reads
-    // (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Speed only: any phase is correct.
-    if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     if (nk > 0) {
 #pragma unroll
         for (int t = 0; t < D; ++t)
@@ -1077,7 +1069,7 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
     // GMD_GEMM_FORCE="bm,bn,pf,ksplit" (0 = keep heuristic): tuning experiments only (tools/bench_gemm.py).  Parsed ONCE per
     // process
     // -- the launch path itself never touches the environment; gmd_gemm_plan_override() changes it in-process for A/B runs.
-    const int fbm = g_force.bm, fbn = g_force.bn, fpf = g_force.pf % 1000, fks = g_force.ks;  // (pf / 1000: stagger experiment)
+    const int fbm = g_force.bm, fbn = g_force.bn, fpf = g_force.pf, fks = g_force.ks;
     if (fbm && fbn) { pl.bm = fbm; pl.bn = fbn; }
     if (fpf) pl.pf = fpf == 9 ? 0 : fpf;  // 9 selects the LDS-DMA pipeline (pf 0)
     int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
@@ -1160,7 +1152,6 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
     const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
     p.ksplit = pl.ksplit;
     p.ws = (float*)ws;
-    p.stagger = g_force.pf / 1000;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
     // the fused GEGLU epilogue pairs value / gate tiles of 16 columns inside a wave: only kernels with an even number of
     // column tiles per wave implement it (the heuristic picks one; a plan override must not bypass that -- the plain
