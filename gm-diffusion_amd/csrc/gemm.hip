@@ -46,6 +46,10 @@ struct GemmParams {
     // taps of a block before the next block.  cblk == Cin is the plain tap-major order.  A smaller block keeps the rows an
     // XCD re-reads for the next tap inside its 4 MiB L2 (see gmd_conv3x3).
     int cblk;
+    // optional column statistics of the stored (rounded) output, for a following GroupNorm: {sum, sum of squares} over each
+    // 64-row block and each bucket of `cs_bucket` adjacent columns -> colstats[M/64][N/cs_bucket][2] (ring kernel, row epilogue)
+    float* colstats;
+    int cs_bucket;
 };
 
 // Row-invariant part of the A address of one staging slot.
@@ -318,6 +322,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
         g0 = mw / p.rows_per_group;
         grem = mw - g0 * p.rows_per_group;
     }
+    float cs[(NCOL + 63) / 64] = {}, cq[(NCOL + 63) / 64] = {};  // column sums of this wave tile (p.colstats only)
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
@@ -358,9 +363,57 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs
             HT* o = (HT*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
-            *reinterpret_cast<uint4*>(o) = make_uint4(Half<HT>::pack2(v[0], v[1]), Half<HT>::pack2(v[2], v[3]), Half<HT>::pack2(v[4], v[5]), Half<HT>::pack2(v[6], v[7]));
+            const uint4 packed = make_uint4(Half<HT>::pack2(v[0], v[1]), Half<HT>::pack2(v[2], v[3]), Half<HT>::pack2(v[4], v[5]), Half<HT>::pack2(v[6], v[7]));
+            *reinterpret_cast<uint4*>(o) = packed;
+            if (p.colstats) {  // the values as stored (rounded) go back to the strip for the column pass below
+                const unsigned pw[4] = {packed.x, packed.y, packed.z, packed.w};
+                float rv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Half<HT>::unpack2(pw[e], rv[2 * e], rv[2 * e + 1]);
+                *reinterpret_cast<float4*>(strip + r * ROWF + c * 8) = make_float4(rv[0], rv[1], rv[2], rv[3]);
+                *reinterpret_cast<float4*>(strip + r * ROWF + c * 8 + 4) = make_float4(rv[4], rv[5], rv[6], rv[7]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
+        if (p.colstats) {  // lane -> column (and column 64 + lane): 32 conflict-free reads each, fixed order
+#pragma unroll
+            for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+                const int cc = lane + 64 * k;
+                if (cc < NCOL) {
+                    float s_ = 0.f, q_ = 0.f;
+#pragma unroll 8
+                    for (int r = 0; r < 32; ++r) {
+                        const float x = strip[r * ROWF + cc];
+                        s_ += x;
+                        q_ += x * x;
+                    }
+                    cs[k] += s_;
+                    cq[k] += q_;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (p.colstats) {  // fold cs_bucket adjacent columns; the wave tile's TM*16 rows are one row block of the statistics
+#pragma unroll
+        for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+            const int cc = lane + 64 * k;
+            if (cc < NCOL) {
+                strip[cc] = cs[k];
+                strip[ROWF + cc] = cq[k];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nb = NCOL / p.cs_bucket;
+        if (lane < nb) {
+            float s_ = 0.f, q_ = 0.f;
+            for (int e = 0; e < p.cs_bucket; ++e) {
+                s_ += strip[lane * p.cs_bucket + e];
+                q_ += strip[ROWF + lane * p.cs_bucket + e];
+            }
+            float* o = p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket + lane) * 2;
+            *reinterpret_cast<float2*>(o) = make_float2(s_, q_);
+        }
     }
 }
 
@@ -1082,6 +1135,12 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
         if (ks > 16) ks = 16;
         if (ks > 1 && (int64_t)ks * M * N * (int64_t)sizeof(float) <= ws_bytes) pl.ksplit = ks;
     }
+    // one workgroup per CU (224..256 large tiles) leaves every SIMD with a single wave; with a very deep K (>= 10240: the
+    // 32x32 up-block convolutions over concatenated inputs) two slices -- two workgroups per CU -- pay for the slab reduction
+    // (tools/bench_graph_ops.py: 1280->640 149.9 -> 137.0 us, 1920->640 208.6 -> 181.1 us; 640->640, K = 5760, loses)
+    if (batch == 1 && pl.bm == 128 && tiles >= 224 && tiles <= 256 && nk >= 160 && !pair_tiles &&
+        2 * (int64_t)M * N * (int64_t)sizeof(float) <= ws_bytes)
+        pl.ksplit = 2;
     // batched, operand-swapped projections (V^T[b] = W_v x_b^T: M = channels <= 640, N = tokens): 128-row tiles leave a
     // ragged third row block at M = 320 and lose to 64x64 tiles even at M = 640 (tools/bench_vt.py: 27.9 -> 18.4 us, 17.2 -> 15.7 us)
     if (pl.ksplit == 1 && batch > 1 && M <= 640 && pl.bm == 128 && !pair_tiles && !(fbm && fbn)) {
@@ -1145,11 +1204,28 @@ hipError_t launch_ring(const GemmParams& p, int gz, hipStream_t s) {
 
 // One 16-bit element type (bf16_t or f16_t): plan, kernel choice, split-K reduction.  float16 instantiates the kernels the
 // heuristic actually picks; the register-staged and deeper-ring tuning variants exist for bfloat16 only (plan overrides).
+// Column statistics (GemmParams::colstats) come out of the row epilogue of the default ring kernels only: every tile must be a
+// full tile of a single, unsplit launch whose waves own 64 rows x (BN/2) columns, a whole number of buckets.
+bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
+    return pl.pf == 0 && pl.bm == 128 && (pl.bn == 160 || pl.bn == 128) && pl.ksplit == 1 && batch == 1 && bucket > 0 &&
+           M % 128 == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0;
+}
+
 template <typename HT, bool CONV>
 int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     constexpr bool kTune = std::is_same<HT, bf16_t>::value;
     hipError_t e = hipSuccess;
     const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
+    if (p.colstats) {
+        const bool rows_ok = !p.out_f32 && p.act != GMD_ACT_GEGLU && (p.ldc & 7) == 0 && (p.residual == nullptr || (p.ldr & 7) == 0) &&
+                             (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0));
+        if (!rows_ok || !colstats_plan_ok(pl, p.M, p.N, batch, p.cs_bucket)) {
+            gmd_set_error("%s: column statistics need the full-tile row epilogue of an unsplit 128-row ring launch "
+                          "(plan %dx%d pf=%d ksplit=%d, M=%d N=%d bucket=%d): ask gmd_gemm_colstats_plan first",
+                          name, pl.bm, pl.bn, pl.pf, pl.ksplit, p.M, p.N, p.cs_bucket);
+            return GMD_ERR_UNSUPPORTED;
+        }
+    }
     p.ksplit = pl.ksplit;
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
@@ -1217,6 +1293,10 @@ template <bool CONV>
 int launch(GemmParams p, int dtype, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     if (dtype == GMD_BF16) return launch_half<bf16_t, CONV>(p, batch, ws, ws_bytes, s, name);
     if (dtype == GMD_F16) return launch_half<f16_t, CONV>(p, batch, ws, ws_bytes, s, name);
+    if (p.colstats) {
+        gmd_set_error("%s: column statistics are implemented for the 16-bit types only", name);
+        return GMD_ERR_UNSUPPORTED;
+    }
     p.ksplit = 1;
     p.ws = nullptr;
     dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
@@ -1239,10 +1319,15 @@ int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit) {
     return GMD_OK;
 }
 
+int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket) {
+    if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 0;
+    return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false), M, N, batch, bucket) ? 1 : 0;
+}
+
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype, int M, int N, int K, int64_t lda,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,
                 const float* rowbias, int rows_per_group, int64_t ldrb, const void* residual, int64_t ldr, int64_t strideR, float alpha,
-                int act, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+                int act, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32, "gmd_gemm_nt: bad dtype %d", dtype);
     const bool is16 = dtype != GMD_F32;
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
@@ -1277,12 +1362,13 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     p.residual = residual; p.ldr = ldr; p.sR = strideR; p.alpha = alpha; p.act = act;
     p.out_f32 = out_dtype == GMD_F32;
     p.cblk = K;
+    p.colstats = colstats; p.cs_bucket = colstats_bucket;
     return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
 }
 
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
                 int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
-                void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+                float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32, "gmd_conv3x3: bad dtype %d", dtype);
     const bool is16 = dtype != GMD_F32;
     GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_conv3x3: out_dtype must be F32 or the input dtype");
@@ -1316,6 +1402,7 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     p.out_f32 = out_dtype == GMD_F32;
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.upsample = upsample; p.pad_lo = pad_lo;
     p.cblk = conv_channel_block(B, Hin, Win, Cin, Cout, dtype);
+    p.colstats = colstats; p.cs_bucket = colstats_bucket;
     return launch<true>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
 }
 

@@ -198,6 +198,79 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
     }
 }
 
+// Apply with the statistics taken from the PRODUCER of X: the GEMM / convolution that wrote X left {sum, sum of squares} per
+// 64-row block and per bucket of `bucket` adjacent channels (gmd_gemm_nt / gmd_conv3x3 `colstats`), so the statistics pass
+// over X -- a third of this operator's traffic and one of its two launches -- disappears.  X may be the channel concatenation
+// of two producers' outputs (the up blocks' skip connections): channels < Ca take their sums from sa [rows/64][Ca/bucket][2],
+// the others from sb [rows/64][(C-Ca)/bucket][2].  Same fold as gn_apply_ws_kernel (8 lanes per group over a fixed strided
+// subset of its (row block, bucket) items, double accumulation, fixed-order shuffle tree): deterministic.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t HW, int C, int G,
+                                                               float eps, const float* __restrict__ sa, int Ca,
+                                                               const float* __restrict__ sb, int bucket,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int silu) {
+    constexpr int V = Elem<T>::kVec;
+    extern __shared__ __attribute__((aligned(16))) float ss[];  // [C][2] = {scale, shift}
+    __shared__ float s_mean[64], s_rstd[64];
+    const int b = blockIdx.y, cpg = C / G;
+    const int rb = (int)(HW / 64), bpg = cpg / bucket, nba = Ca / bucket, nbb = (C - Ca) / bucket;
+    const int items = rb * bpg;
+    for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
+        const int g = g0 + (int)threadIdx.x / 8, sub = threadIdx.x & 7;
+        double s = 0.0, s2 = 0.0;
+        if (g < G) {
+            for (int k = sub; k < items; k += 8) {
+                const int r = k / bpg, kb = g * bpg + (k - r * bpg);
+                const int64_t row = (int64_t)b * rb + r;
+                const float* src = kb < nba ? sa + (row * nba + kb) * 2 : sb + (row * nbb + (kb - nba)) * 2;
+                const float2 o = *reinterpret_cast<const float2*>(src);
+                s += o.x; s2 += o.y;
+            }
+        }
+        s = group8_sum(s);
+        s2 = group8_sum(s2);
+        if (g < G && sub == 0) {
+            const double n = (double)HW * cpg;
+            const double mean = s / n;
+            double var = s2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_mean[g] = (float)mean;
+            s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * gamma[c];
+        ss[2 * c] = sc;
+        ss[2 * c + 1] = beta[c] - s_mean[g] * sc;
+    }
+    __syncthreads();
+    const int CV = C / V;
+    const int64_t per = (HW + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < HW ? r0 + per : HW;
+    const T* Xb = X + ((int64_t)b * HW) * C;
+    T* Yb = Y + ((int64_t)b * HW) * C;
+    for (int64_t i = r0 * CV + threadIdx.x; i < r1 * CV; i += kThreads) {
+        const int chunk = (int)(i % CV);
+        float v[V];
+        load_vec(Xb + i * V, v);
+        const float* q = ss + (size_t)chunk * V * 2;
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {
+            const float4 t = *reinterpret_cast<const float4*>(q + 2 * j);
+            v[j] = v[j] * t.x + t.y;
+            v[j + 1] = v[j + 1] * t.z + t.w;
+        }
+        if (silu) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = silu_f(v[j]);
+        }
+        store_vec(Yb + i * V, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused GroupNorm(+SiLU), one workgroup per (sample, group) over the group's slab [HW][C/G]: exact two-pass mean /
 // variance (fixed reduction order: deterministic) and the normalised result written straight back -- ONE launch
@@ -510,6 +583,34 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
         return GMD_ERR_LAUNCH;
     }
     GMD_CHECK_LAUNCH("gmd_groupnorm_split(apply)");
+    return GMD_OK;
+}
+
+int gmd_groupnorm_colstats(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps, const float* gamma,
+                           const float* beta, const float* stats_a, int Ca, const float* stats_b, int bucket, int silu,
+                           gmd_stream_t stream) {
+    GMD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0, "gmd_groupnorm_colstats: bad shape B=%d HW=%lld C=%d G=%d", B, (long long)HW, C, G);
+    GMD_REQUIRE(X && Y && gamma && beta && stats_a, "gmd_groupnorm_colstats: null pointer");
+    GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y), "gmd_groupnorm_colstats: pointers must be 16-byte aligned");
+    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_groupnorm_colstats: bad dtype %d", dtype);
+    GMD_REQUIRE(B <= 65535, "gmd_groupnorm_colstats: batch too large");
+    const int V = gmd_is_half(dtype) ? 8 : 4;
+    GMD_REQUIRE(C % V == 0 && (size_t)C * 8 <= 64 * 1024, "gmd_groupnorm_colstats: C=%d must be a multiple of %d and at most 8192", C, V);
+    GMD_REQUIRE(HW % 64 == 0, "gmd_groupnorm_colstats: the statistics are per 64-row block, HW=%lld is not a multiple of 64", (long long)HW);
+    GMD_REQUIRE(bucket > 0 && (C / G) % bucket == 0 && Ca > 0 && Ca <= C && Ca % bucket == 0 && (C - Ca) % bucket == 0,
+                "gmd_groupnorm_colstats: bucket=%d must divide the group size %d and both channel ranges (%d, %d)", bucket, C / G, Ca, C - Ca);
+    GMD_REQUIRE(Ca == C || stats_b, "gmd_groupnorm_colstats: statistics of the second channel range are missing");
+    GMD_REQUIRE((reinterpret_cast<uintptr_t>(stats_a) & 7) == 0 && (reinterpret_cast<uintptr_t>(stats_b) & 7) == 0, "gmd_groupnorm_colstats: statistics must be 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nb = (HW + 127) / 128;
+    while (nb * B < 512 && nb < HW) nb *= 2;
+    if (nb > HW) nb = HW;
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        gn_apply_cs_kernel<T><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, eps, stats_a, Ca,
+                                                                                    stats_b, bucket, gamma, beta, silu);
+    });
+    GMD_CHECK_LAUNCH("gmd_groupnorm_colstats");
     return GMD_OK;
 }
 

@@ -425,14 +425,21 @@ class UNet2DConditionModel(_HipModule):
     # ------------------------------------------------------------------------------------------
     def _resnet(self, r, x, B, H, W, temb, eps):
         G = self.config.norm_num_groups
+        cs = self._wants_colstats(H, W)  # the GroupNorm that reads a conv output takes its statistics from the conv epilogue
         h = ops.groupnorm(x, B, G, r["n1"][0], r["n1"][1], eps, silu=True)
-        h, _, _ = ops.conv3x3(h, r["c1"][0], B, H, W, bias=r["c1"][1], rowbias=(temb, r["te_off"]))
+        h, _, _ = ops.conv3x3(h, r["c1"][0], B, H, W, bias=r["c1"][1], rowbias=(temb, r["te_off"]), colstats=cs)
         h = ops.groupnorm(h, B, G, r["n2"][0], r["n2"][1], eps, silu=True)
         if "sc" in r:
             cin = x.shape[-1]
             x = ops.gemm_nt(x.view(-1, cin), r["sc"][0], bias=r["sc"][1]).view(B, H * W, -1)
-        y, _, _ = ops.conv3x3(h, r["c2"][0], B, H, W, bias=r["c2"][1], residual=x)
+        y, _, _ = ops.conv3x3(h, r["c2"][0], B, H, W, bias=r["c2"][1], residual=x, colstats=cs)
         return y
+
+    @staticmethod
+    def _wants_colstats(H, W):
+        """Levels whose GroupNorms take the two-launch split path (hip_ops.groupnorm): there the producer's epilogue
+        statistics replace the statistics launch.  Smaller levels use the single-launch GroupNorm, which needs none."""
+        return H * W >= 1024 and (H * W) % 64 == 0
 
     def _self_attention(self, t, n1, B, N, C):
         heads = self.config.attention_head_dim
@@ -524,7 +531,8 @@ class UNet2DConditionModel(_HipModule):
         else:
             f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
         h = ops.gemm_nt(f, t["ff2"][0], bias=t["ff2"][1], residual=h)
-        return ops.gemm_nt(h, t["pout"][0], bias=t["pout"][1], residual=x.view(B * N, C)).view(B, N, C)
+        y = ops.gemm_nt(h, t["pout"][0], bias=t["pout"][1], residual=x.view(B * N, C), colstats=self._wants_colstats(H, W))
+        return ops.carry_colstats(y.view(B, N, C), y)
 
     def set_timestep(self, timestep):
         """Write the timestep into the device scalar read by the embedding kernel (kept outside any
@@ -567,7 +575,7 @@ class UNet2DConditionModel(_HipModule):
         temb = ops.gemm_nt(te, w["te2"][0], bias=w["te2"][1], act=ops.ACT_SILU)  # = silu(temb): the only use of temb
         temb = ops.gemm_nt(temb, w["te_all"][0], bias=w["te_all"][1], out_dtype=torch.float32)  # [B, sum(Cout)] f32
         Bc = B // 2 if cfg_shared else B  # rows currently carried (the unique half until the first cross-attention)
-        x, _, _ = ops.conv3x3(x, w["conv_in"][0], Bc, H, W, bias=w["conv_in"][1])
+        x, _, _ = ops.conv3x3(x, w["conv_in"][0], Bc, H, W, bias=w["conv_in"][1], colstats=self._wants_colstats(H, W))
         skips = [(x, H, W)]
         for blk in w["down"]:
             for j, r in enumerate(blk["res"]):
@@ -580,7 +588,8 @@ class UNet2DConditionModel(_HipModule):
                         Bc = B
                 skips.append((x, H, W))
             if "ds" in blk:
-                x, H, W = ops.conv3x3(x, blk["ds"][0], B, H, W, bias=blk["ds"][1], stride=2)
+                x, H, W = ops.conv3x3(x, blk["ds"][0], B, H, W, bias=blk["ds"][1], stride=2,
+                                      colstats=self._wants_colstats(H // 2, W // 2))
                 skips.append((x, H, W))
         x = self._resnet(w["mid"]["r0"], x, B, H, W, temb, eps)
         x = self._transformer(w["mid"]["a"], x, B, H, W, ehs)
@@ -592,7 +601,8 @@ class UNet2DConditionModel(_HipModule):
                 if "attn" in blk:
                     x = self._transformer(blk["attn"][j], x, B, H, W, ehs)
             if "us" in blk:
-                x, H, W = ops.conv3x3(x, blk["us"][0], B, H, W, bias=blk["us"][1], upsample=True)
+                x, H, W = ops.conv3x3(x, blk["us"][0], B, H, W, bias=blk["us"][1], upsample=True,
+                                      colstats=self._wants_colstats(2 * H, 2 * W))
         x = ops.groupnorm(x, B, c.norm_num_groups, w["norm_out"][0], w["norm_out"][1], eps, silu=True)
         y, _, _ = ops.conv3x3(x, w["conv_out"][0], B, H, W, bias=w["conv_out"][1], out_dtype=torch.float32)
         return ops.unpack_nchw(y, B, c.out_channels, H, W)

@@ -12,6 +12,8 @@ float32 (parity path); biases / norm parameters / statistics are float32.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import profiling
@@ -136,8 +138,33 @@ def _timed(kind):
 # ----------------------------------------------------------------------------------------------
 # dense contractions
 # ----------------------------------------------------------------------------------------------
+# Column statistics for a following GroupNorm (gmd_hip.h "Column statistics"): a producer launch called with ``colstats=True``
+# leaves {sum, sum of squares} per 64-row block and per bucket of COLSTATS_BUCKET channels when its plan can (the 128-row ring
+# kernels' row epilogue); the tensor it returns then carries them as ``._colstats`` and ``groupnorm`` skips its statistics pass.
+# 10 divides every SD-1.5 group size (320/32, 640/32, 960/32, 1280/32, 1920/32, 2560/32) and half of a 160-column tile.
+COLSTATS_BUCKET = 10
+USE_COLSTATS = os.environ.get("GMD_COLSTATS", "1") != "0"  # A/B switch (tests, tools): off = separate statistics launches
+colstats_uses = 0     # GroupNorm calls served from producer statistics (tests assert the path is really taken)
+
+
+def _colstats_buffer(want, dtype, M, N, K, batch, out_dtype, device):
+    if not want or not USE_COLSTATS or not is_half(dtype) or out_dtype != dtype or M % 64 or N % COLSTATS_BUCKET:
+        return None
+    if not lib().gmd_gemm_colstats_plan(dtype_code(dtype), M, N, K, batch, WORKSPACE_BYTES, COLSTATS_BUCKET):
+        return None
+    return torch.empty((M // 64, N // COLSTATS_BUCKET, 2), dtype=torch.float32, device=device)
+
+
+def carry_colstats(dst, src):
+    """``dst`` is a view of ``src`` with the same rows x channels content: keep the producer statistics attached."""
+    st = getattr(src, "_colstats", None)
+    if st is not None:
+        dst._colstats = st
+    return dst
+
+
 def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=1.0, act=ACT_NONE,
-            out_dtype=None, out=None, ldc=None):
+            out_dtype=None, out=None, ldc=None, colstats=False):
     """``act(alpha * a @ w.T + bias + rowbias[m // rows_per_group] + residual)``.
 
     a: [M, K] or [batch, M, K]; w: [N, K] or [batch, N, K] (a 2-D operand is shared by the batch)."""
@@ -169,19 +196,26 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     if bias is not None and bias.numel() != N:
         raise HipExtensionError("gemm_nt: bias must have N elements")
     ws = _workspace(a.device) if batch == 1 else None
+    st = None
+    if colstats and batch == 1 and a.dim() == 2 and w.dim() == 2 and act != ACT_GEGLU and ldc == N:
+        st = _colstats_buffer(True, a.dtype, M, N, K, 1, out_dtype, a.device)
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("gemm_nt") else None
     t0 = tm.begin() if tm else None
     check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, dtype_code(out_dtype), M, N, K, K, K, ldc, batch, sA, sW, sC,
                             _ptr(_f32(bias, "bias")), rb_ptr, rows_per_group, rb_ld,
-                            _ptr(residual), N, sR, float(alpha), act, _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_gemm_nt")
+                            _ptr(residual), N, sR, float(alpha), act, _ptr(st), COLSTATS_BUCKET if st is not None else 0,
+                            _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_gemm_nt")
     if tm:
         es = a.element_size()
         tm.end("gemm_nt", 2.0 * batch * M * N * K, batch * (M * K + N * K + M * N) * es, t0)
+    if st is not None:
+        out._colstats = (st, N)
     return out
 
 
-def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, upsample=False, pad_mode=0, out_dtype=None):
+def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, upsample=False, pad_mode=0, out_dtype=None,
+            colstats=False):
     """x: [B, H*W, Cin]; w: [Cout, 9*Cin] (tap-major); returns ([B, Hout*Wout, Cout], Hout, Wout)."""
     _dev(x, w, bias, residual)
     rb_ptr, rb_ld = _rowbias(rowbias)
@@ -201,15 +235,19 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     if rowbias is not None and (rowbias[0] if isinstance(rowbias, tuple) else rowbias).shape[0] != B:
         raise HipExtensionError("conv3x3: rowbias must have one row per sample")
     ws = _workspace(x.device)
+    st = _colstats_buffer(colstats, x.dtype, B * ho * wo, cout, 9 * cin, 1, out_dtype, x.device)
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("conv3x3") else None
     t0 = tm.begin() if tm else None
     check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, H, W, cin, cout,
                             stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), rb_ptr, rb_ld,
-                            _ptr(residual), _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_conv3x3")
+                            _ptr(residual), _ptr(st), COLSTATS_BUCKET if st is not None else 0,
+                            _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_conv3x3")
     if tm:
         tm.end("conv3x3", 2.0 * B * ho * wo * cout * 9 * cin, x.numel() * x.element_size() + w.numel() * w.element_size()
                + y.numel() * y.element_size(), t0)
+    if st is not None:
+        y._colstats = (st, cout)
     return y, ho, wo
 
 
@@ -281,9 +319,23 @@ GN_FUSED_MAX_SLAB = 24 * 1024
 GN_FUSED_MAX_SLAB_VEC16 = 40 * 1024
 
 
+def _usable_colstats(x, B, HW, C, cpg):
+    """Producer statistics attached to ``x`` (one producer, or the two halves of a channel concatenation) when they cover
+    exactly this tensor: ((stats_a, Ca), (stats_b, Cb) | None), else None."""
+    st = getattr(x, "_colstats", None)
+    if st is None or HW % 64 or cpg % COLSTATS_BUCKET:
+        return None
+    parts = st if isinstance(st, list) else [st]
+    rows = B * HW // 64
+    if sum(c for _, c in parts) != C or any(t.shape[0] != rows or t.shape[1] * COLSTATS_BUCKET != c for t, c in parts):
+        return None
+    return (parts[0], parts[1] if len(parts) == 2 else None) if len(parts) <= 2 else None
+
+
 def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
-    """GroupNorm(+SiLU).  Small group slabs (16x16 / 8x8 UNet levels) take the single-launch fused kernel;
-    larger ones the split-statistics path (partial + finalize + apply)."""
+    """GroupNorm(+SiLU).  A tensor that still carries its producer's column statistics (``colstats=True`` of gemm_nt /
+    conv3x3, possibly through concat_channels) is normalised in one pass over it; otherwise small group slabs (16x16 / 8x8
+    UNet levels) take the single-launch fused kernel and larger ones the split-statistics path (partial + apply)."""
     _dev(x, gamma, beta)
     C = x.shape[-1]
     HW = x.numel() // (B * C)
@@ -293,6 +345,20 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
     # algorithmic HBM bytes of a GroupNorm: the activation is read once and written once (the statistics pass of the split
     # path re-reads it: that second read is what the roofline fraction of this kind exposes)
     nbytes = 2 * x.numel() * x.element_size()
+    st = _usable_colstats(x, B, HW, C, cpg)
+    if st is not None:
+        global colstats_uses
+        colstats_uses += 1
+        (sa, ca), sb = st
+        y = torch.empty_like(x)
+        tm, t0 = _timed("groupnorm")
+        check(lib().gmd_groupnorm_colstats(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps),
+                                           _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(sa), ca,
+                                           _ptr(sb[0]) if sb is not None else None, COLSTATS_BUCKET, int(silu), _stream()),
+              "gmd_groupnorm_colstats")
+        if tm:
+            tm.end("groupnorm", 0.0, nbytes, t0)
+        return y
     if cpg % epw == 0 and HW * cpg * x.element_size() <= (GN_FUSED_MAX_SLAB_VEC16 if vec16 else GN_FUSED_MAX_SLAB):
         y = torch.empty_like(x)
         tm, t0 = _timed("groupnorm")
@@ -358,6 +424,9 @@ def concat_channels(a, b):
           "gmd_concat_channels")
     if tm:
         tm.end("concat", 0.0, 2 * out.numel() * out.element_size(), t0)
+    sa, sb = getattr(a, "_colstats", None), getattr(b, "_colstats", None)
+    if sa is not None and sb is not None and not isinstance(sa, list) and not isinstance(sb, list):
+        out._colstats = [sa, sb]  # a following GroupNorm reads the two producers' statistics side by side
     return out
 
 
@@ -563,7 +632,7 @@ def gemm_raw(a_ptr, w_ptr, c_ptr, dtype, out_dtype, M, N, K, lda, ldw, ldc, batc
     a_ptr/w_ptr/c_ptr are integer device addresses; the caller keeps the owning tensors alive."""
     _dev(bias)
     check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, dtype_code(dtype), dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
-                            sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, 0, None, 0, 0, float(alpha), act, None, 0, _stream()),
+                            sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, 0, None, 0, 0, float(alpha), act, None, 0, None, 0, _stream()),
           "gmd_gemm_nt")
 
 

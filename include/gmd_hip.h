@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 4
+#define GMD_ABI_VERSION 5
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -184,7 +184,18 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 int batch, int64_t strideA, int64_t strideW, int64_t strideC,
                 const float* bias, const float* rowbias, int rows_per_group, int64_t ldrb,
                 const void* residual, int64_t ldr, int64_t strideR,
-                float alpha, int act, void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
+                float alpha, int act, float* colstats, int colstats_bucket,
+                void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
+
+/* Column statistics for a following GroupNorm (diffusers GroupNorm over a ResnetBlock2D / Transformer2DModel input: the
+ * statistics pass is folded into the epilogue of the launch that produces the tensor).  With `colstats` non-NULL,
+ * gmd_gemm_nt / gmd_conv3x3 also write float32 colstats[M/64][N/colstats_bucket][2] = {sum, sum of squares} of the STORED
+ * (rounded) outputs over each block of 64 rows and each bucket of `colstats_bucket` adjacent columns, in a fixed order.
+ * Only launches that run the full-tile row epilogue of the 128-row ring kernels can do this (16-bit types, batch 1, no
+ * split-K, M % 128 == 0, N a multiple of the 160- or 128-column tile, bucket dividing half a tile): this returns 1 when a
+ * launch of these dimensions will, 0 otherwise (asking for colstats then fails with GMD_ERR_UNSUPPORTED).  For a
+ * convolution pass M = B*Hout*Wout, N = Cout, K = 9*Cin. */
+int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket);
 
 /* 3x3 convolution, padding 1, as an implicit GEMM over channels-last data.
  * X: [B,Hin,Win,Cin]; Wt: [Cout, 9*Cin] with k = (ky*3+kx)*Cin + c; Y: [B,Hout,Wout,Cout].
@@ -195,6 +206,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype,
                 int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode,
                 const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
+                float* colstats, int colstats_bucket,
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
 
 /* Flash-style attention, bf16 MFMA: O = softmax(scale * Q K^T) V per (batch, head).
@@ -230,6 +242,13 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
                         const float* gamma, const float* beta, float* workspace, int silu, gmd_stream_t stream);
 int gmd_groupnorm_apply(const void* X, void* Y, int dtype, int B, int64_t HW, int C,
                         const float* scale_shift, int silu, gmd_stream_t stream);
+/* GroupNorm(+SiLU) in ONE pass over X, with the statistics its producer(s) left (`colstats` of gmd_gemm_nt / gmd_conv3x3,
+ * one row block per 64 rows: HW % 64 == 0).  X may be the channel concatenation of two producers' outputs (UNet skip
+ * connections): channels [0, Ca) use stats_a [B*HW/64][Ca/bucket][2], channels [Ca, C) stats_b [B*HW/64][(C-Ca)/bucket][2]
+ * (NULL when Ca == C).  bucket must divide C/G, Ca and C-Ca. */
+int gmd_groupnorm_colstats(const void* X, void* Y, int dtype, int B, int64_t HW, int C, int G, float eps,
+                           const float* gamma, const float* beta, const float* stats_a, int Ca,
+                           const float* stats_b, int bucket, int silu, gmd_stream_t stream);
 /* GroupNorm(+SiLU) in ONE launch: one workgroup per (sample, group) over the group's [HW][C/G] slab (exact two-pass
  * variance, fixed reduction order; the slab is re-read from L2).  Returns GMD_ERR_UNSUPPORTED when the slab exceeds
  * 128 KiB: use gmd_groupnorm_stats + gmd_groupnorm_apply then. */

@@ -748,3 +748,117 @@ def test_plan_override_cannot_bypass_geglu_tile_rule():
     finally:
         lib().gmd_gemm_plan_override(0, 0, 0, 0)
     assert rel_err(got.float(), want.float()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupNorm statistics out of the producer's epilogue
+# ---------------------------------------------------------------------------------------------
+def _bucket_sums(y, bucket):
+    """float64 {sum, sumsq} of the stored values per 64-row block and per bucket of adjacent columns."""
+    M, N = y.shape
+    v = y.double().cpu().view(M // 64, 64, N // bucket, bucket)
+    return torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("kind", ["conv_res", "conv_rowbias", "conv_up", "gemm_res"])
+def test_colstats_from_producer_epilogue(dtype, kind):
+    """``colstats=True``: the launch that writes a tensor also leaves the per-(64 rows x 10 channels) sums of the values it
+    STORED -- compared with float64 sums of the stored tensor itself, so rounding is not part of the error."""
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    if kind == "gemm_res":
+        M, N, K = 16384, 320, 320
+        a = (torch.randn(M, K, generator=g) * 0.5).to(DEV, dtype)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, dtype)
+        res = torch.randn(M, N, generator=g).to(DEV, dtype)
+        bias = torch.randn(N, generator=g).to(DEV)
+        y = o.gemm_nt(a, w, bias=bias, residual=res, colstats=True)
+        plain = o.gemm_nt(a, w, bias=bias, residual=res)
+    else:
+        B, H, W, cin, cout = 4, 64, 64, 64, 320
+        if kind == "conv_up":
+            H = W = 32
+        x = torch.randn(B, H * W, cin, generator=g).to(DEV, dtype)
+        w = (torch.randn(cout, 9 * cin, generator=g) * 0.04).to(DEV, dtype)
+        bias = torch.randn(cout, generator=g).to(DEV)
+        kw = {}
+        if kind == "conv_res":
+            kw["residual"] = torch.randn(B, 64 * 64, cout, generator=g).to(DEV, dtype)
+        if kind == "conv_rowbias":
+            kw["rowbias"] = torch.randn(B, cout, generator=g).to(DEV)
+        if kind == "conv_up":
+            kw["upsample"] = True
+        y, _, _ = o.conv3x3(x, w, B, H, W, bias=bias, colstats=True, **kw)
+        plain, _, _ = o.conv3x3(x, w, B, H, W, bias=bias, **kw)
+    assert torch.equal(y, plain)  # the statistics do not touch the output
+    st, C = y._colstats
+    assert C == y.shape[-1] and st.dtype == torch.float32
+    ref = _bucket_sums(y.view(-1, C), o.COLSTATS_BUCKET)
+    assert tuple(st.shape) == tuple(ref.shape)
+    assert rel_err(st, ref) < 2e-6 and max_err(st[..., 0], ref[..., 0]) < 2e-3
+
+
+def test_colstats_only_where_the_plan_has_the_row_epilogue():
+    """Small / split-K / 64x64-tile launches cannot emit statistics: the front end then attaches none (GroupNorm falls back
+    to its own statistics launch), and forcing the request through the C ABI fails loudly instead of leaving them unwritten."""
+    from gm_diffusion import _native
+
+    o = ops()
+    lib = _native.lib()
+    code = o.dtype_code(torch.bfloat16)
+    assert lib.gmd_gemm_colstats_plan(code, 32768, 320, 2880, 1, o.WORKSPACE_BYTES, 10) == 1
+    assert lib.gmd_gemm_colstats_plan(code, 2048, 1280, 11520, 1, o.WORKSPACE_BYTES, 10) == 0  # split-K
+    assert lib.gmd_gemm_colstats_plan(code, 512, 320, 320, 1, o.WORKSPACE_BYTES, 10) == 0      # 64x64 tiles
+    assert lib.gmd_gemm_colstats_plan(code, 32768, 320, 2880, 1, o.WORKSPACE_BYTES, 32) == 0   # 80 % 32 != 0
+    assert lib.gmd_gemm_colstats_plan(o.dtype_code(torch.float32), 32768, 320, 2880, 1, o.WORKSPACE_BYTES, 10) == 0
+    a = torch.randn(512, 320, device=DEV).bfloat16()
+    w = torch.randn(320, 320, device=DEV).bfloat16()
+    assert not hasattr(o.gemm_nt(a, w, colstats=True), "_colstats")
+    out = torch.empty(512, 320, device=DEV, dtype=torch.bfloat16)
+    st = torch.zeros(8, 32, 2, device=DEV)
+    rc = lib.gmd_gemm_nt(a.data_ptr(), w.data_ptr(), out.data_ptr(), code, code, 512, 320, 320, 320, 320, 320, 1, 0, 0, 0, None, None, 0,
+                         0, None, 0, 0, 1.0, 0, st.data_ptr(), 10, None, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 3 and b"column statistics" in lib.gmd_last_error()
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("Ca,Cb,silu", [(320, 0, True), (640, 320, True), (320, 320, False), (1280, 640, True)])
+def test_groupnorm_from_producer_colstats(dtype, Ca, Cb, silu):
+    """GroupNorm fed by producer statistics (one producer, or the two halves of a skip concatenation whose groups straddle
+    the seam: 960 / 32 = 30 channels per group over a 640 | 320 split) against float64 GroupNorm of the same stored tensor
+    and against the kernel's own statistics path."""
+    o = ops()
+    g = torch.Generator().manual_seed(Ca + Cb)
+    B, HW, G = 2, 1024, 32
+    C = Ca + Cb
+
+    def produce(c, seed):
+        gg = torch.Generator().manual_seed(seed)
+        a = (torch.randn(B * HW, 320, generator=gg) * 0.5).to(DEV, dtype)
+        w = (torch.randn(c, 320, generator=gg) * 0.08).to(DEV, dtype)
+        bias = (torch.randn(c, generator=gg) * 2.0).to(DEV)  # non-zero means: exercises the E[x^2] - E[x]^2 form
+        # M = 2048 is too small for the ring kernel alone: run the producer on 8 stacked copies and keep the first
+        big = o.gemm_nt(a.repeat(8, 1), w, bias=bias, colstats=True)
+        st, _ = big._colstats
+        y = big[: B * HW].contiguous().view(B, HW, c)
+        y._colstats = (st[: B * HW // 64].contiguous(), c)
+        return y
+
+    ya = produce(Ca, 1)
+    x = ya
+    if Cb:
+        x = o.concat_channels(ya, produce(Cb, 2))
+        assert isinstance(x._colstats, list)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    before = o.colstats_uses
+    got = o.groupnorm(x, B, G, gamma, beta, 1e-5, silu=silu)
+    assert o.colstats_uses == before + 1
+    xs = x.clone()  # a fresh tensor carries no statistics: the kernel's own two-launch path
+    assert not hasattr(xs, "_colstats")
+    own = o.groupnorm(xs, B, G, gamma, beta, 1e-5, silu=silu)
+    assert o.colstats_uses == before + 1
+    ref = F.group_norm(x.double().cpu().permute(0, 2, 1), G, gamma.double().cpu(), beta.double().cpu(), 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_err(got, ref) < tol(dtype) and rel_err(got, own) < 1e-3

@@ -223,3 +223,31 @@ def test_unet_cfg_shared_prefix_equals_duplicated_batch(dtype, tol):
     gph = hu.graphed_forward(6, 16, 16, c, cfg_shared=True)
     hu.pack_input(lat.to(DEV), dup=1, out=gph.x)
     assert torch.equal(gph.replay(), shared)
+
+
+def test_sd15_unet_bf16_producer_statistics_path_vs_oracle_and_vs_statistics_launch():
+    """Full-width SD-1.5 UNet at the benchmark's latent size (64x64, batch 4): the GroupNorms of the two upper levels take
+    their statistics from the epilogue of the convolution / projection that produced their input.  Same forward with the
+    switch off (separate statistics launches) and the CPU oracle as references."""
+    from gm_diffusion import hip_ops as ops
+    from oracle import fixtures
+
+    ou = fixtures.build_unet("sd15", 8)
+    hu = _hip_unet(ou, torch.bfloat16)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(4, 8, 64, 64, generator=g)
+    ctx = torch.randn(4, 77, 768, generator=g)
+    ref = ou(x, torch.tensor(501), encoder_hidden_states=ctx)[0]
+    before = ops.colstats_uses
+    got = hu(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
+    used = ops.colstats_uses - before
+    assert used >= 16, used  # every GroupNorm of the 64x64 level (at batch 4 the 32x32 level's launches are too small to emit)
+    ops.USE_COLSTATS = False
+    try:
+        plain = hu(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
+        assert ops.colstats_uses - before == used
+    finally:
+        ops.USE_COLSTATS = True
+    e_ref, e_plain = rel_err(got, ref), rel_err(plain, ref)
+    assert e_ref < 3e-2 and e_plain < 3e-2 and e_ref < 1.25 * e_plain + 1e-3, (e_ref, e_plain)
+    assert rel_err(got, plain) < 1.5e-2
