@@ -30,6 +30,8 @@ struct AttnParams {
     float scale_log2;  // softmax scale * log2(e)
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int KV = 64;      // keys per tile
 constexpr int VROW = 136;   // bytes per V^T LDS row: 64 keys * 2 B + 8 B pad (conflict-free b64 reads)
 constexpr float kNegBig = -1.0e30f;
@@ -420,6 +422,362 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Head dim 40 (the 64x64-level self-attention of SD-1.5 -- three quarters of all attention time -- and its 77-key
+// cross-attention): the same transposed formulation, with the K / V^T tiles brought in by LDS-DMA instead of through
+// registers.  Measured on the kernel above (B=8, N=4096): with the staging of tiles 1.. removed the launch takes 236 us
+// instead of 303 us -- the register prefetch is issued after the softmax (the 128-VGPR budget has no room earlier) and
+// consumed at the end of the same tile, which exposes most of an L2 round trip per tile.  Here a tile is requested TWO
+// tiles ahead into a 3-stage LDS ring (`buffer_load_dwordx4 ... lds`, counted vmcnt, one barrier per tile) and costs no
+// registers at all.  What the lane-linear DMA image dictates:
+//   * K rows are dense (80 B = 5 slots of 16 B: an odd stride, so the ds_read_b128 fragment reads stay conflict-free);
+//     the stabiliser column K[key][40] = 1 of the lagged softmax cannot live in the rows any more -- the lanes that would
+//     read d = 40..47 read one constant 16-byte vector {1, 0 x 7} of the stage instead (same address: a broadcast).
+//   * V^T rows are 128 B (64 keys) with the 16-byte chunk index XOR (row >> 1) & 7, applied to the per-lane SOURCE address
+//     of the DMA and to the reads.  Each lane fetches the 8 keys of a k-step as ONE ds_read_b128 (two ds_read_b64 before):
+//     lane r of the first product reads K row (r with bits 2 and 3 swapped), which makes the 8 values a lane holds for a
+//     k-step of the second product 8 CONSECUTIVE keys (16 ks + 8 (lane>>5) + j) instead of two groups of four.
+//   * the padding rows of V^T (row 40 = ones: the softmax row sum on the matrix core; rows 41.. = zeros) are two constant
+//     rows per stage that the lanes of d >= 40 address directly.
+// Keys at and beyond Nk in the last tile: K rows come back as zeros (the tile offset moves into the range-checked per-lane
+// offset for that tile) and are masked after the first product; V^T columns are zeroed in LDS before use.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename HT>
+__global__ __launch_bounds__(256, 4) void attn40_kernel(const AttnParams p) {
+    constexpr int D = 40, DK = 3, DT = 2, NST = 3;
+    constexpr int KROWB = 2 * D;                 // dense K row, bytes
+    constexpr int kLagOff = KV * KROWB;          // {1.0, 0 x 7}
+    constexpr int kVOff = 5376;                  // V^T rows (128 B each), 256-byte aligned
+    constexpr int kStage = kVOff + (D + 2) * 128;  // + the ones row and the zero row
+    static_assert(kLagOff + 16 <= kVOff && kStage % 256 == 0, "stage layout");
+    constexpr float kLagMax = std::is_same<HT, f16_t>::value ? 14.0f : 20.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+    const int r = lane & 31, hh = lane >> 5;
+    int qb, head, b;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int qq = nwg >> 3, rr = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + j;
+        const int nqb = (p.Nq + 127) / 128;
+        qb = L % nqb;
+        const int t = L / nqb;
+        head = t % p.H;
+        b = t / p.H;
+    }
+    const int q = qb * 128 + wid * 32 + r;
+    const bool qvalid = q < p.Nq;
+    const bf16_t* Qb = p.Q + (int64_t)b * p.sQ + (int64_t)head * D;
+    const bf16_t* Kb = p.K + (int64_t)b * p.sK + (int64_t)head * D;
+    const bf16_t* Vb = p.Vt + (int64_t)b * p.sVt + (int64_t)head * D * p.ldvt;
+
+    // constant parts of the three stages
+    for (int i = tid; i < NST * 24; i += 256) {
+        const int st = i / 24, e = i - st * 24;
+        unsigned char* base = smem + st * kStage;
+        if (e < 8) {
+            const unsigned one2 = Half<HT>::kOne | (Half<HT>::kOne << 16);
+            *reinterpret_cast<uint4*>(base + kVOff + D * 128 + e * 16) = make_uint4(one2, one2, one2, one2);
+        } else if (e < 16) {
+            *reinterpret_cast<uint4*>(base + kVOff + (D + 1) * 128 + (e - 8) * 16) = make_uint4(0, 0, 0, 0);
+        } else if (e == 16) {
+            *reinterpret_cast<uint4*>(base + kLagOff) = make_uint4(Half<HT>::kOne, 0, 0, 0);
+        }
+    }
+
+    // Q fragments (B operand of the first product), pre-multiplied by scale * log2(e)
+    uint4 qf[DK];
+#pragma unroll
+    for (int s = 0; s < DK; ++s) {
+        const int d0 = 16 * s + 8 * hh;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (qvalid && d0 + 8 <= D) v = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * p.ldq + d0);
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float lo, hi;
+            Half<HT>::unpack2(w[j], lo, hi);
+            w[j] = Half<HT>::pack2(lo * p.scale_log2, hi * p.scale_log2);
+        }
+        qf[s] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    f32x16 ot[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[t][i] = 0.f;
+    float m_run = 0.f;
+    int lag_overflow = 0;
+    auto set_stabiliser = [&](float m_new) {  // Q[q][40] = -m: fragment 2, lanes of the upper half, element 0
+        m_run = m_new;
+        const unsigned nm = Half<HT>::pack2(-m_new, 0.0f) & 0xffffu;
+        qf[2].x = hh == 1 ? ((qf[2].x & 0xffff0000u) | nm) : qf[2].x;
+    };
+
+    // ---- per-lane LDS read offsets inside a stage (tile-invariant; the stage is an immediate) ----
+    const int kr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);  // K row read by first-product row r (bits 2 <-> 3)
+    const int kb = kr * KROWB + hh * 16;                           // k-steps 0, 1 at +32 s; second key block at +32 * KROWB
+    const int kl0 = hh ? kLagOff : kr * KROWB + 64;                // k-step 2: d 32..39, or the stabiliser vector
+    const int kl1 = hh ? kLagOff : (32 + kr) * KROWB + 64;
+    int v0[4], v1[4];
+    {
+        const int fsw = (r >> 1) & 7;
+        const int vr = r < 8 ? 32 + r : (r == 8 ? D : D + 1);     // d = 32 + r: real row, ones row, zero row
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + hh;
+            v0[ks] = kVOff + r * 128 + ((c ^ fsw) << 4);
+            v1[ks] = kVOff + vr * 128 + (((r < 8) ? (c ^ fsw) : (c ^ 4)) << 4);  // constant rows: any chunk; this one avoids the real rows' banks
+        }
+    }
+
+    // ---- DMA plan: 640 16-byte chunks per tile (K 320 + V^T 320) = three pieces per thread, the third for waves 0, 1 ----
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    u32x4 dK, dV;
+    {
+        const uint64_t bk = (uint64_t)Kb, bv = (uint64_t)Vb;
+        const unsigned kbytes = (unsigned)((((int64_t)p.Nk - 1) * p.ldk + D) * 2);
+        const unsigned vbytes = (unsigned)((((int64_t)D - 1) * p.ldvt + (p.Nk + 7) / 8 * 8) * 2);
+        dK = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bk), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bk >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(kbytes), 0x00020000u};
+        dV = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bv), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bv >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(vbytes), 0x00020000u};
+    }
+    auto k_src = [&](int g) { const int key = g / 5, c = g - key * 5; return (unsigned)(key * (int)p.ldk + c * 8) * 2u; };
+    auto v_src = [&](int v) { const int d = v >> 3, c = (v & 7) ^ ((d >> 1) & 7); return (unsigned)(d * (int)p.ldvt + c * 8) * 2u; };
+    const unsigned off0 = k_src(tid);                                             // K chunks 0..255
+    const unsigned off1 = wuni == 0 ? k_src(tid + 256) : v_src(tid - 64);         // wave 0: K 256..319; waves 1-3: V^T 0..191
+    const unsigned off2 = v_src(tid + 192);                                       // waves 0, 1: V^T 192..319
+    const unsigned dst0 = (unsigned)wuni * 1024u;
+    const unsigned dst1 = wuni == 0 ? 4096u : (unsigned)kVOff + (unsigned)(wuni - 1) * 1024u;
+    const unsigned dst2 = (unsigned)kVOff + 3072u + (unsigned)wuni * 1024u;
+    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                     :
+                     : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                     : "memory", "m0");
+#pragma clang diagnostic pop
+    };
+    const int ntiles = (p.Nk + KV - 1) / KV;
+    auto issue = [&](int kt, int stage) {
+        const int k0 = kt * KV;
+        unsigned ks_off = (unsigned)k0 * (unsigned)p.ldk * 2u, vs_off = (unsigned)k0 * 2u;
+        unsigned a0 = off0, a1 = off1, a2 = off2;
+        if (k0 + KV > p.Nk) {  // last, partial tile (wave-uniform): the tile offset joins the range-checked per-lane offset
+            a0 += ks_off;
+            a1 += wuni == 0 ? ks_off : vs_off;
+            a2 += vs_off;
+            ks_off = vs_off = 0;
+        }
+        const unsigned sb = lds_base + (unsigned)stage * kStage;
+        dma16(dK, sb + dst0, a0, ks_off);
+        if (wuni == 0) dma16(dK, sb + dst1, a1, ks_off);
+        else dma16(dV, sb + dst1, a1, vs_off);
+        if (wuni < 2) dma16(dV, sb + dst2, a2, vs_off);
+    };
+    // wait until this wave's pieces of the oldest tile in flight have landed (`more`: a younger tile stays in flight)
+    auto wait_tile = [&](bool more) {
+        if (!more) attn_wait_vmcnt<0>();
+        else if (wuni < 2) attn_wait_vmcnt<3>();
+        else attn_wait_vmcnt<2>();
+    };
+    auto first_product = [&](const unsigned char* Sb, int t) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            acc = Half<HT>::mfma32(*reinterpret_cast<const uint4*>(Sb + kb + t * (32 * KROWB) + 32 * s), qf[s], acc);
+        return Half<HT>::mfma32(*reinterpret_cast<const uint4*>(Sb + (t ? kl1 : kl0)), qf[2], acc);
+    };
+
+    // one K / V^T tile out of ring stage STAGE
+    auto tile = [&](const int kt, auto stage_c, auto lag_c) {
+        constexpr bool LAG = decltype(lag_c)::value;
+        constexpr int STAGE = decltype(stage_c)::value;
+        const int k0 = kt * KV;
+        wait_tile(kt + 1 < ntiles);
+        __syncthreads();  // every wave's pieces of tile kt are in LDS; every wave is done reading tile kt-1
+        const unsigned char* Sb = smem + STAGE * kStage;
+        if (k0 + KV > p.Nk) {  // block-uniform: zero the V^T columns of keys >= Nk (whatever follows them in memory)
+            for (int id = tid; id < D * 8; id += 256) {
+                const int d = id >> 3, c = (id & 7) ^ ((d >> 1) & 7);
+                const int nv = p.Nk - (k0 + c * 8);  // valid keys in this chunk
+                if (nv < 8) {
+                    uint4* cell = reinterpret_cast<uint4*>(smem + STAGE * kStage + kVOff + id * 16);
+                    const uint4 x = *cell;
+                    unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (2 * e >= nv) w[e] = 0;
+                        else if (2 * e + 1 >= nv) w[e] &= 0xffffu;
+                    }
+                    *cell = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            __syncthreads();
+        }
+        if (kt + 2 < ntiles) issue(kt + 2, (STAGE + 2) % NST);  // that stage held tile kt-1
+
+        f32x16 st[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) st[t] = first_product(Sb, t);
+        // register i of key block t, lane half hh  <->  key k0 + 32 t + 16 (i >> 3) + 8 hh + (i & 7)
+        if (k0 + KV > p.Nk) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = k0 + 32 * t + 16 * (i >> 3) + 8 * hh + (i & 7);
+                    if (key >= p.Nk) st[t][i] = kNegBig;
+                }
+        }
+        float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, st[0][i]), st[1][i]);
+        mx = half_swap_max(mx);
+        float alpha;
+        if constexpr (LAG) {
+            lag_overflow |= mx > kLagMax;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[t][i] = __builtin_amdgcn_exp2f(st[t][i]);
+            const float m_new = Half<HT>::round(m_run + fmaxf(mx, 0.f));
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            set_stabiliser(m_new);
+        } else {
+            // classic maximum-first softmax (only after a stabiliser overflow): Q[q][40] = 0, scores are scale*log2e*q.k
+            const float m_new = fmaxf(m_run, mx);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[t][i] = __builtin_amdgcn_exp2f(st[t][i] - m_new);
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ot[t][i] *= alpha;
+            }
+        }
+        uint4 pf[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 w;
+                w.x = Half<HT>::pack2(st[t][8 * s + 0], st[t][8 * s + 1]);
+                w.y = Half<HT>::pack2(st[t][8 * s + 2], st[t][8 * s + 3]);
+                w.z = Half<HT>::pack2(st[t][8 * s + 4], st[t][8 * s + 5]);
+                w.w = Half<HT>::pack2(st[t][8 * s + 6], st[t][8 * s + 7]);
+                pf[2 * t + s] = w;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            ot[0] = Half<HT>::mfma32(*reinterpret_cast<const uint4*>(Sb + v0[ks]), pf[ks], ot[0]);
+            ot[1] = Half<HT>::mfma32(*reinterpret_cast<const uint4*>(Sb + v1[ks]), pf[ks], ot[1]);
+        }
+        if constexpr (LAG) {
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ot[t][i] *= alpha;
+            }
+        }
+    };
+    auto run = [&](auto lag_c) {
+        constexpr bool LAG = decltype(lag_c)::value;
+        issue(0, 0);
+        if (ntiles > 1) issue(1, 1);
+        if constexpr (LAG) {
+            // initial stabiliser: the maximum of the first tile's scores (one extra first product)
+            wait_tile(ntiles > 1);
+            __syncthreads();
+            float mx = kNegBig;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x16 s0 = first_product(smem, t);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * t + 16 * (i >> 3) + 8 * hh + (i & 7);
+                    if (key < p.Nk) mx = fmaxf(mx, s0[i]);
+                }
+            }
+            mx = half_swap_max(mx);
+            set_stabiliser(Half<HT>::round(mx));
+        }
+        for (int kt = 0; kt < ntiles; kt += 3) {
+            tile(kt, std::integral_constant<int, 0>{}, lag_c);
+            if (kt + 1 < ntiles) tile(kt + 1, std::integral_constant<int, 1>{}, lag_c);
+            if (kt + 2 < ntiles) tile(kt + 2, std::integral_constant<int, 2>{}, lag_c);
+        }
+    };
+    run(std::true_type{});
+    // A score more than 2^kLagMax above the lagged stabiliser could overflow exp2: redo the whole block with the classic
+    // (maximum-first) softmax.  Block-wide decision (it is also the barrier that ends the last tile's LDS reads).
+    if (__syncthreads_or(lag_overflow)) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ot[t][i] = 0.f;
+        set_stabiliser(0.f);
+        m_run = kNegBig;
+        run(std::false_type{});
+        __syncthreads();
+    }
+
+    // ---- normalise and store (as above): row 40 of O^T is the softmax row sum ----
+    const float l_tot = __shfl(ot[1][4], r, 64);  // d = 40: tile 1, register 4 * ((40 % 32) / 8), lanes of the lower half
+    const float inv = 1.0f / l_tot;
+    constexpr int SROW = D * 2 + 16;
+    unsigned char* strip = smem + wid * (32 * SROW);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 32 * dt + 8 * g + 4 * hh;
+            if (d0 < D) {
+                uint2 w;
+                w.x = Half<HT>::pack2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
+                w.y = Half<HT>::pack2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(strip + r * SROW + d0 * 2) = w;
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CH = D / 8;
+    const int q0w = qb * 128 + wid * 32;
+    bf16_t* Ow = p.O + (int64_t)b * p.sO + (int64_t)q0w * p.ldo + (int64_t)head * D;
+#pragma unroll
+    for (int t = 0; t < (32 * CH + 63) / 64; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / CH, cc = idx - rr * CH;
+        if (rr < 32 && q0w + rr < p.Nq)
+            *reinterpret_cast<uint4*>(Ow + (int64_t)rr * p.ldo + cc * 8) = *reinterpret_cast<const uint4*>(strip + rr * SROW + cc * 16);
+    }
+}
+
+template <typename HT>
+int launch_attn40(const AttnParams& p, int B, int H, hipStream_t s) {
+    constexpr size_t smem = 3 * (5376 + 42 * 128);
+    dim3 grid(((p.Nq + 127) / 128) * H * B, 1, 1);
+    attn40_kernel<HT><<<grid, 256, smem, s>>>(p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gmd_set_error("gmd_attention: launch failed: %s", hipGetErrorString(e));
+        return GMD_ERR_LAUNCH;
+    }
+    return GMD_OK;
+}
+
 template <typename HT, int D, bool CAUSAL = false>
 int launch_attn(const AttnParams& p, int B, int H, hipStream_t s) {
     constexpr int DK = (D + 15) / 16, DT = (D + 31) / 32;
@@ -445,7 +803,7 @@ int dispatch_attn(const AttnParams& p, int B, int H, int D, int Nq, int Nk, int 
     }
     switch (D) {
         case 32: return launch_attn<HT, 32>(p, B, H, s);
-        case 40: return launch_attn<HT, 40>(p, B, H, s);
+        case 40: return launch_attn40<HT>(p, B, H, s);
         case 64: return launch_attn<HT, 64>(p, B, H, s);
         case 80: return launch_attn<HT, 80>(p, B, H, s);
         case 160: return launch_attn<HT, 160>(p, B, H, s);
