@@ -42,6 +42,17 @@ for M, N, K in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192
     r = torch.randn(M, N, generator=g).bfloat16().cuda()
     cases.append((f"gemm M={M} N={N} K={K}", 2.0 * M * N * K, lambda a=a, w=w, b=b, r=r: ops.gemm_nt(a, w, bias=b, residual=r)))
 
+for M, N, K in [(32768, 2560, 320), (8192, 5120, 640), (2048, 10240, 1280)]:
+    a = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    cases.append((f"geglu M={M} N={N} K={K}", 2.0 * M * N * K, lambda a=a, w=w, b=b: ops.gemm_nt(a, w, bias=b, act=ops.ACT_GEGLU)))
+x = torch.randn(8, 64 * 64, 320, generator=g).bfloat16().cuda()
+w3 = (torch.randn(320, 9 * 320, generator=g) * 0.02).bfloat16().cuda()
+tb = torch.randn(8, 320, generator=g).cuda()
+rs = torch.randn(8, 64 * 64, 320, generator=g).bfloat16().cuda()
+cases.append(("conv B=8 64x64 320->320 rowbias+res", 2.0 * 32768 * 320 * 2880, lambda: ops.conv3x3(x, w3, 8, 64, 64, bias=tb[0].contiguous(), rowbias=tb, residual=rs)[0]))
+
 print(f"{'case':52s} {'default':>16s} " + " ".join(f"{v:>22s}" for v in variants))
 for name, fl, fn in cases:
     force()
