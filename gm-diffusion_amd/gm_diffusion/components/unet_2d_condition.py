@@ -496,6 +496,9 @@ class UNet2DConditionModel(_HipModule):
         out = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         out[: t.shape[0]].copy_(t)
         out[t.shape[0]:].copy_(t)
+        st = getattr(t, "_colstats", None)
+        if st is not None and not isinstance(st, list):  # producer statistics are per 64-row block, sample-major: duplicate alike
+            out._colstats = (torch.cat([st[0], st[0]], 0), st[1])
         return out
 
     def _transformer(self, t, x, B, H, W, ehs, cfg_dup=False):
