@@ -18,6 +18,11 @@
 
 #include <type_traits>
 
+// attention_split.hip: float32 tensors, three float16 MFMA passes per contraction (GMD_F32S)
+int gmd_launch_attention_split(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int D, int Nq, int Nk, int64_t ldq,
+                               int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQ, int64_t sK, int64_t sVt, int64_t sO, float scale,
+                               hipStream_t stream);
+
 namespace {
 
 struct AttnParams {
@@ -818,8 +823,23 @@ int dispatch_attn(const AttnParams& p, int B, int H, int D, int Nq, int Nk, int 
 extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void* O, int dtype, int B, int H, int D, int Nq,
                              int Nk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t strideQ, int64_t strideK,
                              int64_t strideVt, int64_t strideO, float scale, int causal, gmd_stream_t stream) {
+    if (dtype == GMD_F32S) {  // float32 tensors, both contractions as three float16 products (attention_split.hip)
+        GMD_REQUIRE(!causal, "gmd_attention: the float32 (split) kernel has no causal mask");
+        GMD_REQUIRE(B >= 0 && H > 0 && Nq >= 0 && Nk > 0, "gmd_attention: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+        if (B == 0 || Nq == 0) return GMD_OK;
+        GMD_REQUIRE((int64_t)((Nq + 127) / 128) * H * B < (1ll << 31), "gmd_attention: grid too large");
+        GMD_REQUIRE(Q && K && Vt && O && gmd_aligned16(Q) && gmd_aligned16(K) && gmd_aligned16(Vt) && gmd_aligned16(O),
+                    "gmd_attention: null or unaligned pointer");
+        GMD_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldvt % 4 == 0 && ldo % 4 == 0 && strideQ % 4 == 0 && strideK % 4 == 0 && strideVt % 4 == 0 &&
+                        strideO % 4 == 0, "gmd_attention: float32 leading dimensions / batch strides must be multiples of 4");
+        GMD_REQUIRE((int64_t)Nk * ldk < (1ll << 29) && (int64_t)D * ldvt < (1ll << 29), "gmd_attention: K / V^T slab of one head exceeds 2 GiB");
+        GMD_REQUIRE(ldvt >= ((Nk + 3) / 4) * 4, "gmd_attention: ldvt=%lld must cover Nk=%d rounded up to 4", (long long)ldvt, Nk);
+        GMD_REQUIRE(ldq >= (int64_t)H * D && ldk >= (int64_t)H * D && ldo >= (int64_t)H * D, "gmd_attention: row stride smaller than H*D");
+        return gmd_launch_attention_split(Q, K, Vt, O, B, H, D, Nq, Nk, ldq, ldk, ldvt, ldo, strideQ, strideK, strideVt, strideO, scale,
+                                          (hipStream_t)stream);
+    }
     if (dtype != GMD_BF16 && dtype != GMD_F16) {
-        gmd_set_error("gmd_attention: only GMD_BF16 / GMD_F16 are implemented (the F32 parity path composes gmd_gemm_nt + gmd_softmax_rows)");
+        gmd_set_error("gmd_attention: GMD_BF16 / GMD_F16 / GMD_F32S are implemented (the exact F32 path composes gmd_gemm_nt + gmd_softmax_rows)");
         return GMD_ERR_UNSUPPORTED;
     }
     GMD_REQUIRE(B >= 0 && H > 0 && Nq >= 0 && Nk > 0, "gmd_attention: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);

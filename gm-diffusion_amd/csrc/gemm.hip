@@ -15,107 +15,15 @@
 //
 // For conv3x3 the GEMM row m is the output pixel (b, oy, ox), k = (ky*3+kx)*Cin + c; the A tile is
 // gathered on the fly (zero padding, stride 2, fused nearest-2x upsample) -- no im2col buffer.
-#include "gmd_common.h"
+#include "gemm_shared.h"
 #include <stdlib.h>
-#include <mutex>
 #include <type_traits>
 
+// gemm_split.hip: float32 on the matrix cores as three float16 products (GMD_F32S / GMD_F32SW)
+int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
+int gmd_launch_split_conv(const void* params, int w_presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
+
 namespace {
-
-struct GemmParams {
-    const void* A;
-    const void* W;
-    void* C;
-    int M, N, K;
-    int64_t lda, ldw, ldc, sA, sW, sC;
-    const float* bias;
-    const float* rowbias;
-    int rows_per_group;
-    int64_t ldrb;        // row stride of rowbias (>= N)
-    const void* residual;
-    int64_t ldr, sR;
-    float alpha;
-    int act;
-    int out_f32;
-    unsigned a_bytes, w_bytes;  // extents of the A / W operands (one batch slab) for the buffer descriptors
-    int ksplit;          // > 1: grid z splits K; raw fp32 partial sums go to `ws` [ksplit][M][N], epilogue in splitk_reduce
-    float* ws;
-    // conv3x3 geometry (CONV instantiations only)
-    int Hin, Win, Cin, Hout, Wout, stride, upsample, pad_lo;
-    // conv3x3 K order of the ring kernel: channels are walked in blocks of `cblk` (a multiple of 64 dividing Cin), all nine
-    // taps of a block before the next block.  cblk == Cin is the plain tap-major order.  A smaller block keeps the rows an
-    // XCD re-reads for the next tap inside its 4 MiB L2 (see gmd_conv3x3).
-    int cblk;
-    // optional column statistics of the stored (rounded) output, for a following GroupNorm: {sum, sum of squares} over each
-    // 64-row block and each bucket of `cs_bucket` adjacent columns -> colstats[M/64][N/cs_bucket][2] (ring kernel, row epilogue)
-    float* colstats;
-    int cs_bucket;
-};
-
-// Row-invariant part of the A address of one staging slot.
-struct RowCtx {
-    bool valid;
-    int b, oy, ox;         // conv: output pixel
-    int64_t base;          // gemm: element offset of the row start
-};
-
-template <bool CONV>
-__device__ __forceinline__ RowCtx make_row(const GemmParams& p, int m) {
-    RowCtx r;
-    r.valid = m < p.M;
-    r.b = r.oy = r.ox = 0;
-    r.base = 0;
-    if (!r.valid) return r;
-    if (CONV) {
-        const int hw = p.Hout * p.Wout;
-        r.b = m / hw;
-        const int rem = m - r.b * hw;
-        r.oy = rem / p.Wout;
-        r.ox = rem - r.oy * p.Wout;
-    } else {
-        r.base = (int64_t)m * p.lda;
-    }
-    return r;
-}
-
-// element offset into A of (row, k-step starting at channel c0 of tap (ky,kx)), or -1 for padding
-template <bool CONV>
-__device__ __forceinline__ int64_t a_offset(const GemmParams& p, const RowCtx& r, int k0, int ky, int kx, int c0) {
-    if (!r.valid) return -1;
-    if (!CONV) return r.base + k0;
-    int iy, ix;
-    if (p.upsample) {
-        const int uy = r.oy + ky - 1, ux = r.ox + kx - 1;
-        if (uy < 0 || ux < 0 || uy >= 2 * p.Hin || ux >= 2 * p.Win) return -1;
-        iy = uy >> 1;
-        ix = ux >> 1;
-    } else {
-        iy = r.oy * p.stride + ky - p.pad_lo;
-        ix = r.ox * p.stride + kx - p.pad_lo;
-        if (iy < 0 || ix < 0 || iy >= p.Hin || ix >= p.Win) return -1;
-    }
-    return (((int64_t)r.b * p.Hin + iy) * p.Win + ix) * p.Cin + c0;
-}
-
-// erf for the bf16 GEGLU epilogue: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (two orders below bf16 rounding) in ~14
-// instructions (one v_rcp, one v_exp) instead of libm's branchy erff -- the epilogue of the K=320 ff1 GEMM evaluates 32 of
-// them per thread for only 5 K steps of MFMA work.  The float32 parity path (gmd_geglu) keeps erff.
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float y = fmaf(1.061405429f, t, -1.453152027f);
-    y = fmaf(y, t, 1.421413741f);
-    y = fmaf(y, t, -0.284496736f);
-    y = fmaf(y, t, 0.254829592f);
-    y = y * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    return copysignf(1.0f - y, x);
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == GMD_ACT_SILU) return silu_f(v);
-    if (act == GMD_ACT_QUICK_GELU) return v / (1.0f + __expf(-1.702f * v));
-    return v;
-}
 
 // Fused epilogue for 8 consecutive columns n..n+7 of row m (bf16 activations): alpha, bias, per-group row
 // bias, residual, activation, then a 16-byte store (scalar stores on ragged / unaligned edges).
@@ -186,12 +94,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int BK = 64;  // bf16 elements per K step = 128 bytes = 8 chunks of 16 bytes
-
-// byte offset of 16-byte chunk `chunk` of row `row` in a [rows][128 B] tile; the XOR makes both the
-// 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups of a 16x16x32 fragment conflict-free
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
 // Epilogue straight from registers.  The MFMA operands are swapped (W fragment as A, activation fragment as B), so
 // by the C/D layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds FOUR CONSECUTIVE output columns n of ONE
 // row m: bias/row-bias/residual/activation are applied in registers and each lane stores 8 bytes (bf16) or 16 bytes
@@ -493,32 +395,6 @@ __device__ __forceinline__ void epilogue_rows_geglu(const GemmParams& p, const f
     }
 }
 
-template <int V> struct IntC { static constexpr int value = V; };
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOOB = 0xFFFF0000u;  // byte offset beyond every buffer (extents are checked < kOOB on the host)
-
-// Operand addressing of the bf16 kernel: every staging slot keeps ONE 32-bit byte offset into a raw buffer
-// resource; rows beyond M/N and conv padding taps hold kOOB, for which the buffer load returns zeros -- no
-// branches and no 64-bit arithmetic in the K loop.  For conv3x3 the offsets are recomputed only when the
-// K loop crosses into the next filter tap (every Cin/64 steps).
-template <bool CONV>
-__device__ __forceinline__ unsigned conv_tap_offset(const GemmParams& p, bool valid, int b, int oy, int ox, int ky, int kx, int chunk) {
-    if (!valid) return kOOB;
-    int iy, ix;
-    if (p.upsample) {
-        const int uy = oy + ky - 1, ux = ox + kx - 1;
-        if (uy < 0 || ux < 0 || uy >= 2 * p.Hin || ux >= 2 * p.Win) return kOOB;
-        iy = uy >> 1;
-        ix = ux >> 1;
-    } else {
-        iy = oy * p.stride + ky - p.pad_lo;
-        ix = ox * p.stride + kx - p.pad_lo;
-        if (iy < 0 || ix < 0 || iy >= p.Hin || ix >= p.Win) return kOOB;
-    }
-    return (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin) * 2u + (unsigned)chunk * 16u;
-}
-
 // PF = register prefetch distance in K steps: the global loads of tile kt+PF are issued before the MFMAs of
 // tile kt and are written to LDS at the end of iteration kt+PF-1, i.e. they have PF whole iterations to land.
 template <typename HT, bool CONV, int BM, int BN, int PF>
@@ -788,7 +664,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 //                  issue DMA of tile kt+NST-1 into stage (kt-1)%NST
 //                  MFMAs on stage kt%NST
 // ------------------------------------------------------------------------------------------------
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename HT, bool CONV, int WM, int WN, int TN, int NST>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void gemm_ring_kernel(const GemmParams p) {
@@ -1155,28 +1030,6 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
     return pl;
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-(function, device) property: remember it per device, so a
-// process that drives several GPUs (not the one-process-per-GPU design, but legal) opts in on each of them.
-hipError_t opt_in_lds(const void* fn, int bytes) {
-    constexpr int kMaxDev = 64, kMaxFn = 64;
-    static const void* fns[kMaxFn];
-    static unsigned long long done[kMaxFn];  // bit d: set on device d
-    static std::mutex mu;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lock(mu);
-    int slot = -1;
-    for (int i = 0; i < kMaxFn; ++i) {
-        if (fns[i] == fn) { slot = i; break; }
-        if (fns[i] == nullptr) { fns[i] = fn; slot = i; break; }
-    }
-    if (slot >= 0 && dev < kMaxDev && (done[slot] >> dev & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess && slot >= 0 && dev < kMaxDev) done[slot] |= 1ull << dev;
-    return e;
-}
-
 template <typename HT, bool CONV, int BM, int BN, int PF>
 hipError_t launch_bf16(const GemmParams& p, int gz, hipStream_t s) {
     constexpr size_t smem = 2 * (BM + BN) * 128;
@@ -1328,12 +1181,13 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,
                 const float* rowbias, int rows_per_group, int64_t ldrb, const void* residual, int64_t ldr, int64_t strideR, float alpha,
                 int act, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32, "gmd_gemm_nt: bad dtype %d", dtype);
-    const bool is16 = dtype != GMD_F32;
-    GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
+    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;  // float32 tensors, three float16 MFMA passes
+    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32 || split, "gmd_gemm_nt: bad dtype %d", dtype);
+    const bool is16 = gmd_is_half(dtype);
+    GMD_REQUIRE(out_dtype == GMD_F32 || (!split && out_dtype == dtype), "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
     GMD_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gmd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     if (M == 0 || N == 0 || batch == 0) return GMD_OK;
-    const int kmul = is16 ? 64 : 4, vec = is16 ? 8 : 4;
+    const int kmul = is16 ? 64 : split ? 32 : 4, vec = is16 ? 8 : 4;
     GMD_REQUIRE(K % kmul == 0, "gmd_gemm_nt: K=%d must be a multiple of %d", K, kmul);
     GMD_REQUIRE(lda >= K && ldw >= K && (ldc >= N || act == GMD_ACT_GEGLU), "gmd_gemm_nt: leading dimension too small");
     GMD_REQUIRE(lda % vec == 0 && ldw % vec == 0 && strideA % vec == 0 && strideW % vec == 0,
@@ -1342,7 +1196,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     GMD_REQUIRE(bias == nullptr || gmd_aligned16(bias), "gmd_gemm_nt: bias must be 16-byte aligned (it is read with float4 loads)");
     GMD_REQUIRE(rowbias == nullptr || rows_per_group > 0, "gmd_gemm_nt: rows_per_group must be positive");
     GMD_REQUIRE(residual == nullptr || (ldr >= N && gmd_aligned16(residual)), "gmd_gemm_nt: bad residual");
-    GMD_REQUIRE(residual == nullptr || out_dtype == dtype || dtype == GMD_F32, "gmd_gemm_nt: residual needs out_dtype == dtype");
+    GMD_REQUIRE(residual == nullptr || out_dtype == dtype || !is16, "gmd_gemm_nt: residual needs out_dtype == dtype");
     GMD_REQUIRE(act == GMD_ACT_NONE || act == GMD_ACT_SILU || act == GMD_ACT_GEGLU || act == GMD_ACT_QUICK_GELU, "gmd_gemm_nt: bad act %d", act);
     if (act == GMD_ACT_GEGLU) {
         GMD_REQUIRE(is16 && out_dtype == dtype, "gmd_gemm_nt: GEGLU epilogue is implemented for the 16-bit types only");
@@ -1354,8 +1208,9 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = strideA; p.sW = strideW; p.sC = strideC;
     {
-        const int64_t ab = ((int64_t)(M - 1) * lda + K) * 2, wb = ((int64_t)(N - 1) * ldw + K) * 2;
-        GMD_REQUIRE(!is16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_gemm_nt: operand slab larger than 4 GiB");
+        const int es = is16 ? 2 : 4;
+        const int64_t ab = ((int64_t)(M - 1) * lda + K) * es, wb = ((int64_t)(N - 1) * ldw + K) * es;
+        GMD_REQUIRE(!(is16 || split) || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_gemm_nt: operand slab larger than 4 GiB");
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     }
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.ldrb = ldrb > 0 ? ldrb : N;
@@ -1363,26 +1218,31 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     p.out_f32 = out_dtype == GMD_F32;
     p.cblk = K;
     p.colstats = colstats; p.cs_bucket = colstats_bucket;
+    if (split) {
+        GMD_REQUIRE(!colstats, "gmd_gemm_nt: column statistics are implemented for the 16-bit types only");
+        return gmd_launch_split_gemm(&p, dtype == GMD_F32SW, batch, batch == 1 ? workspace : nullptr, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
+    }
     return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
 }
 
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
                 int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
-                float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
-    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32, "gmd_conv3x3: bad dtype %d", dtype);
-    const bool is16 = dtype != GMD_F32;
-    GMD_REQUIRE(out_dtype == dtype || out_dtype == GMD_F32, "gmd_conv3x3: out_dtype must be F32 or the input dtype");
+                float alpha, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;
+    GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32 || split, "gmd_conv3x3: bad dtype %d", dtype);
+    const bool is16 = gmd_is_half(dtype);
+    GMD_REQUIRE(out_dtype == GMD_F32 || (!split && out_dtype == dtype), "gmd_conv3x3: out_dtype must be F32 or the input dtype");
     GMD_REQUIRE(B >= 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "gmd_conv3x3: bad shape");
     if (B == 0) return GMD_OK;  // empty batch
     GMD_REQUIRE(stride == 1 || stride == 2, "gmd_conv3x3: stride must be 1 or 2");
     GMD_REQUIRE(!(upsample && stride != 1), "gmd_conv3x3: upsample requires stride 1");
     GMD_REQUIRE(pad_mode == 0 || (pad_mode == 1 && stride == 2 && !upsample), "gmd_conv3x3: pad_mode 1 requires stride 2");
-    const int kmul = is16 ? 64 : 16;
+    const int kmul = is16 ? 64 : split ? 32 : 16;
     GMD_REQUIRE(Cin % kmul == 0, "gmd_conv3x3: Cin=%d must be a multiple of %d (pad the channels)", Cin, kmul);
     GMD_REQUIRE(X && Wt && Y && gmd_aligned16(X) && gmd_aligned16(Wt) && gmd_aligned16(Y), "gmd_conv3x3: null or unaligned pointer");
     GMD_REQUIRE(bias == nullptr || gmd_aligned16(bias), "gmd_conv3x3: bias must be 16-byte aligned (it is read with float4 loads)");
     GMD_REQUIRE(residual == nullptr || gmd_aligned16(residual), "gmd_conv3x3: unaligned residual");
-    GMD_REQUIRE(residual == nullptr || out_dtype == dtype, "gmd_conv3x3: residual needs out_dtype == dtype");
+    GMD_REQUIRE(residual == nullptr || out_dtype == dtype || !is16, "gmd_conv3x3: residual needs out_dtype == dtype");
     int Hout, Wout, pad_lo;
     if (upsample) { Hout = 2 * Hin; Wout = 2 * Win; pad_lo = 1; }
     else if (pad_mode == 1) { Hout = (Hin + 1 - 3) / 2 + 1; Wout = (Win + 1 - 3) / 2 + 1; pad_lo = 0; }
@@ -1393,16 +1253,21 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     p.A = X; p.W = Wt; p.C = Y; p.M = (int)M; p.N = Cout; p.K = 9 * Cin;
     p.lda = Cin; p.ldw = 9 * (int64_t)Cin; p.ldc = Cout;
     {
-        const int64_t ab = (int64_t)B * Hin * Win * Cin * 2, wb = (int64_t)Cout * 9 * Cin * 2;
-        GMD_REQUIRE(!is16 || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_conv3x3: tensor larger than 4 GiB");
+        const int es = is16 ? 2 : 4;
+        const int64_t ab = (int64_t)B * Hin * Win * Cin * es, wb = (int64_t)Cout * 9 * Cin * es;
+        GMD_REQUIRE(!(is16 || split) || (ab < 0xFFFF0000LL && wb < 0xFFFF0000LL), "gmd_conv3x3: tensor larger than 4 GiB");
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     }
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = Hout * Wout; p.ldrb = ldrb > 0 ? ldrb : Cout;
-    p.residual = residual; p.ldr = Cout; p.alpha = 1.0f; p.act = GMD_ACT_NONE;
+    p.residual = residual; p.ldr = Cout; p.alpha = alpha; p.act = GMD_ACT_NONE;
     p.out_f32 = out_dtype == GMD_F32;
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.upsample = upsample; p.pad_lo = pad_lo;
     p.cblk = conv_channel_block(B, Hin, Win, Cin, Cout, dtype);
     p.colstats = colstats; p.cs_bucket = colstats_bucket;
+    if (split) {
+        GMD_REQUIRE(!colstats, "gmd_conv3x3: column statistics are implemented for the 16-bit types only");
+        return gmd_launch_split_conv(&p, dtype == GMD_F32SW, B, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
+    }
     return launch<true>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
 }
 

@@ -1,0 +1,160 @@
+// Pieces shared by the dense-contraction translation units (gemm.hip: 16-bit and exact float32 kernels; gemm_split.hip:
+// float32 on the matrix cores as three float16 products): parameter block, operand addressing, LDS image, activation.
+#pragma once
+#include "gmd_common.h"
+#include <mutex>
+
+namespace {
+
+struct GemmParams {
+    const void* A;
+    const void* W;
+    void* C;
+    int M, N, K;
+    int64_t lda, ldw, ldc, sA, sW, sC;
+    const float* bias;
+    const float* rowbias;
+    int rows_per_group;
+    int64_t ldrb;        // row stride of rowbias (>= N)
+    const void* residual;
+    int64_t ldr, sR;
+    float alpha;
+    int act;
+    int out_f32;
+    unsigned a_bytes, w_bytes;  // extents of the A / W operands (one batch slab) for the buffer descriptors
+    int ksplit;          // > 1: grid z splits K; raw fp32 partial sums go to `ws` [ksplit][M][N], epilogue in splitk_reduce
+    float* ws;
+    // conv3x3 geometry (CONV instantiations only)
+    int Hin, Win, Cin, Hout, Wout, stride, upsample, pad_lo;
+    // conv3x3 K order of the ring kernel: channels are walked in blocks of `cblk` (a multiple of 64 dividing Cin), all nine
+    // taps of a block before the next block.  cblk == Cin is the plain tap-major order.  A smaller block keeps the rows an
+    // XCD re-reads for the next tap inside its 4 MiB L2 (see gmd_conv3x3).
+    int cblk;
+    // optional column statistics of the stored (rounded) output, for a following GroupNorm: {sum, sum of squares} over each
+    // 64-row block and each bucket of `cs_bucket` adjacent columns -> colstats[M/64][N/cs_bucket][2] (ring kernel, row epilogue)
+    float* colstats;
+    int cs_bucket;
+};
+
+// Row-invariant part of the A address of one staging slot.
+struct RowCtx {
+    bool valid;
+    int b, oy, ox;         // conv: output pixel
+    int64_t base;          // gemm: element offset of the row start
+};
+
+template <bool CONV>
+__device__ __forceinline__ RowCtx make_row(const GemmParams& p, int m) {
+    RowCtx r;
+    r.valid = m < p.M;
+    r.b = r.oy = r.ox = 0;
+    r.base = 0;
+    if (!r.valid) return r;
+    if (CONV) {
+        const int hw = p.Hout * p.Wout;
+        r.b = m / hw;
+        const int rem = m - r.b * hw;
+        r.oy = rem / p.Wout;
+        r.ox = rem - r.oy * p.Wout;
+    } else {
+        r.base = (int64_t)m * p.lda;
+    }
+    return r;
+}
+
+// element offset into A of (row, k-step starting at channel c0 of tap (ky,kx)), or -1 for padding
+template <bool CONV>
+__device__ __forceinline__ int64_t a_offset(const GemmParams& p, const RowCtx& r, int k0, int ky, int kx, int c0) {
+    if (!r.valid) return -1;
+    if (!CONV) return r.base + k0;
+    int iy, ix;
+    if (p.upsample) {
+        const int uy = r.oy + ky - 1, ux = r.ox + kx - 1;
+        if (uy < 0 || ux < 0 || uy >= 2 * p.Hin || ux >= 2 * p.Win) return -1;
+        iy = uy >> 1;
+        ix = ux >> 1;
+    } else {
+        iy = r.oy * p.stride + ky - p.pad_lo;
+        ix = r.ox * p.stride + kx - p.pad_lo;
+        if (iy < 0 || ix < 0 || iy >= p.Hin || ix >= p.Win) return -1;
+    }
+    return (((int64_t)r.b * p.Hin + iy) * p.Win + ix) * p.Cin + c0;
+}
+
+// erf for the bf16 GEGLU epilogue: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (two orders below bf16 rounding) in ~14
+// instructions (one v_rcp, one v_exp) instead of libm's branchy erff -- the epilogue of the K=320 ff1 GEMM evaluates 32 of
+// them per thread for only 5 K steps of MFMA work.  The float32 parity path (gmd_geglu) keeps erff.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    y = y * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(1.0f - y, x);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == GMD_ACT_SILU) return silu_f(v);
+    if (act == GMD_ACT_QUICK_GELU) return v / (1.0f + __expf(-1.702f * v));
+    return v;
+}
+
+constexpr int BK = 64;  // bf16 elements per K step = 128 bytes = 8 chunks of 16 bytes
+
+// byte offset of 16-byte chunk `chunk` of row `row` in a [rows][128 B] tile; the XOR makes both the
+// 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups of a 16x16x32 fragment conflict-free
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int V> struct IntC { static constexpr int value = V; };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0xFFFF0000u;  // byte offset beyond every buffer (extents are checked < kOOB on the host)
+
+// Operand addressing of the bf16 kernel: every staging slot keeps ONE 32-bit byte offset into a raw buffer
+// resource; rows beyond M/N and conv padding taps hold kOOB, for which the buffer load returns zeros -- no
+// branches and no 64-bit arithmetic in the K loop.  For conv3x3 the offsets are recomputed only when the
+// K loop crosses into the next filter tap (every Cin/64 steps).
+template <bool CONV>
+__device__ __forceinline__ unsigned conv_tap_offset(const GemmParams& p, bool valid, int b, int oy, int ox, int ky, int kx, int chunk) {
+    if (!valid) return kOOB;
+    int iy, ix;
+    if (p.upsample) {
+        const int uy = oy + ky - 1, ux = ox + kx - 1;
+        if (uy < 0 || ux < 0 || uy >= 2 * p.Hin || ux >= 2 * p.Win) return kOOB;
+        iy = uy >> 1;
+        ix = ux >> 1;
+    } else {
+        iy = oy * p.stride + ky - p.pad_lo;
+        ix = ox * p.stride + kx - p.pad_lo;
+        if (iy < 0 || ix < 0 || iy >= p.Hin || ix >= p.Win) return kOOB;
+    }
+    return (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin) * 2u + (unsigned)chunk * 16u;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-(function, device) property: remember it per device, so a
+// process that drives several GPUs (not the one-process-per-GPU design, but legal) opts in on each of them.
+hipError_t opt_in_lds(const void* fn, int bytes) {
+    constexpr int kMaxDev = 64, kMaxFn = 64;
+    static const void* fns[kMaxFn];
+    static unsigned long long done[kMaxFn];  // bit d: set on device d
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    int slot = -1;
+    for (int i = 0; i < kMaxFn; ++i) {
+        if (fns[i] == fn) { slot = i; break; }
+        if (fns[i] == nullptr) { fns[i] = fn; slot = i; break; }
+    }
+    if (slot >= 0 && dev < kMaxDev && (done[slot] >> dev & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && slot >= 0 && dev < kMaxDev) done[slot] |= 1ull << dev;
+    return e;
+}
+
+}  // namespace

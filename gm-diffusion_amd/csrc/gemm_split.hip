@@ -1,0 +1,582 @@
+// float32 contractions on the matrix cores: every float32 operand x is taken as hi + lo with hi = f16(x) and
+// lo = f16(x - hi) (22 significand bits between them) and a product a*b is formed as three float16 MFMA passes
+//     a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (a_lo*b_lo, <= 2^-22 of the product, is dropped)
+// with float32 accumulation inside the MFMA.  Products of two 11-bit significands are exact in float32, so the result
+// differs from an exact float32 FMA chain by ~2^-22 relative per term -- the same order as float32 rounding itself --
+// at one third of the float16 matrix rate instead of the 1/16 the float32 vector units (gemm_f32_kernel) or the
+// f32-input MFMA forms offer.  This is the path that meets the reference's float32 numerics (the reference only ever
+// runs the dual-UNet pipeline in float32: scripts/inference/experiments/formal_improved.py:199) on the matrix cores.
+//
+//   C[m, n] = act(alpha * sum_k A[m, k] * W[n, k] + bias[n] + rowbias[m / rpg, n] + residual[m, n])      (all float32)
+//
+// Same operand addressing, LDS-DMA ring, XCD-aware tile order, conv3x3 implicit GEMM and split-K slabs as
+// gemm_ring_kernel (gemm.hip); what differs:
+//   * a K step is 32 elements: a tile row is 128 bytes of float32 (A, and W when it is given as plain float32) or
+//     64 bytes hi + 64 bytes lo of a PRE-SPLIT weight (gmd_split_weights: done once when a model is placed on the device);
+//   * fragments are split in registers after the LDS read: v_cvt_pk_f16_f32 for hi, v_fma_mix_f32 (x - hi with the
+//     f16 operand converted on the fly) and a second v_cvt_pk_f16_f32 for lo: 16 vector instructions per 8-element
+//     fragment against the 12 (TN = 4) or 15 (TN = 5) MFMAs that consume it;
+//   * lane group q of a 16x16x32 MFMA owns k = {4q..4q+3, 16+4q..16+4q+3} of the step (both operands alike, so the sum
+//     over k is unchanged): its two 16-byte float32 chunks are q and q+4, the conflict-free pattern of lds_off();
+//   * range: an operand beyond the float16 range (|x| > 65504) becomes infinite -- the limit of the float16 path; the
+//     exact kernel (GMD_F32) has no such limit and stays available.
+#include "gemm_shared.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BKS = 32;  // float32 elements per K step = 128 bytes
+
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+// (a, b) -> packed f16 pair hi and packed f16 pair lo = f16(x - hi)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f16x2_t h = {(_Float16)a, (_Float16)b};  // v_cvt_pk_f16_f32, round to nearest even
+    const unsigned hw = __builtin_bit_cast(unsigned, h);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hw), "v"(a));                  // a - f32(h.lo)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hw), "v"(b));  // b - f32(h.hi)
+    const f16x2_t l = {(_Float16)ra, (_Float16)rb};
+    hi = hw;
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split8(const float4& x0, const float4& x1, uint4& hi, uint4& lo) {
+    split2(x0.x, x0.y, hi.x, lo.x);
+    split2(x0.z, x0.w, hi.y, lo.y);
+    split2(x1.x, x1.y, hi.z, lo.z);
+    split2(x1.z, x1.w, hi.w, lo.w);
+}
+__device__ __forceinline__ f32x4 mfma_h(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// byte offset of (pixel, tap) of a float32 channels-last image, or kOOB for padding (see conv_tap_offset in gemm_shared.h)
+__device__ __forceinline__ unsigned conv_tap_offset_f32(const GemmParams& p, bool valid, int b, int oy, int ox, int ky, int kx, int chunk) {
+    if (!valid) return kOOB;
+    int iy, ix;
+    if (p.upsample) {
+        const int uy = oy + ky - 1, ux = ox + kx - 1;
+        if (uy < 0 || ux < 0 || uy >= 2 * p.Hin || ux >= 2 * p.Win) return kOOB;
+        iy = uy >> 1;
+        ix = ux >> 1;
+    } else {
+        iy = oy * p.stride + ky - p.pad_lo;
+        ix = ox * p.stride + kx - p.pad_lo;
+        if (iy < 0 || ix < 0 || iy >= p.Hin || ix >= p.Win) return kOOB;
+    }
+    return (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin) * 4u + (unsigned)chunk * 16u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogues (float32 in, float32 out)
+// ------------------------------------------------------------------------------------------------
+// From registers: a lane holds four consecutive columns of one row (operands swapped as in gemm.hip).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_regs_f32(const GemmParams& p, const f32x4 (&acc)[TM][TN], int mw, int nw, int frow, int fq, int z,
+                                                  int ks) {
+    const bool vec_c = (p.ldc % 4 == 0) && (p.sC % 4 == 0);
+    const bool vec_r = p.residual != nullptr && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
+    const bool vec_n = (p.N % 4 == 0);
+    const bool vec_rb = vec_n && (p.ldrb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mw + i * 16 + frow;
+        if (m >= p.M) continue;
+        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nw + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            const int nvalid = p.N - n < 4 ? p.N - n : 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.ksplit > 1) {  // raw partial sums; the epilogue runs in splitk_reduce_f32_kernel
+                float* o = p.ws + ((int64_t)ks * p.M + m) * p.N + n;
+                if (nvalid == 4 && vec_n) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+                continue;
+            }
+            float add[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                if (nvalid == 4 && vec_n) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
+                    add[0] = t.x; add[1] = t.y; add[2] = t.z; add[3] = t.w;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) add[e] = p.bias[n + e];
+                }
+            }
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) {
+                const float* res = (const float*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n;
+                if (nvalid == 4 && vec_r) {
+                    const float4 t = *reinterpret_cast<const float4*>(res);
+                    rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) rv[e] = res[e];
+                }
+            }
+            if (rb) {
+                if (nvalid == 4 && vec_rb) {
+                    const float4 t = *reinterpret_cast<const float4*>(rb + n);
+                    rv[0] += t.x; rv[1] += t.y; rv[2] += t.z; rv[3] += t.w;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) rv[e] += rb[n + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + add[e] + rv[e], p.act);
+            float* o = (float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+            if (nvalid == 4 && vec_c) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+        }
+    }
+}
+
+// Row-contiguous form through a per-wave LDS strip (full tiles): the store path is transaction-bound, so the
+// accumulators are parked in LDS, read back row-major and leave as 16-byte stores over whole 64*TN-byte row segments, the
+// residual read in the same shape.  SLAB: raw partial sums into this slice's split-K slab instead (no epilogue terms).
+// Strip rows are 16 rows at a time per TM tile pair: 32 rows x (TN*16 + 4) floats per wave.
+template <int TM, int TN, bool SLAB>
+__device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
+                                                  int z, int ks) {
+    static_assert(TM % 2 == 0, "halves of two 16-row tiles");
+    constexpr int NCOL = TN * 16, ROWF = NCOL + 4, CH = NCOL / 4;
+    constexpr int ITER = (32 * CH + 63) / 64;
+    const int frow = lane & 15, fq = lane >> 4;
+    int g0 = 0, grem = 0;
+    if (!SLAB && p.rowbias) {
+        g0 = mw / p.rows_per_group;
+        grem = mw - g0 * p.rows_per_group;
+    }
+    float* slab = SLAB ? p.ws + (int64_t)ks * p.M * p.N : nullptr;
+#pragma unroll
+    for (int h = 0; h < TM / 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + j * 16 + fq * 4) =
+                    make_float4(acc[2 * h + i2][j][0], acc[2 * h + i2][j][1], acc[2 * h + i2][j][2], acc[2 * h + i2][j][3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < ITER; ++t) {
+            const int idx = lane + 64 * t;
+            const int r = idx / CH, c = idx - r * CH;
+            if (32 * CH % 64 != 0 && r >= 32) continue;
+            const int m = mw + h * 32 + r, n = nw + c * 4;
+            const float4 a = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 4);
+            if (SLAB) {
+                *reinterpret_cast<float4*>(slab + (int64_t)m * p.N + n) = a;
+                continue;
+            }
+            float v[4] = {a.x, a.y, a.z, a.w};
+            float add[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) {
+                const float4 w = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
+                add[0] = w.x; add[1] = w.y; add[2] = w.z; add[3] = w.w;
+            }
+            if (p.rowbias) {
+                const int ro = h * 32 + r;
+                const int grp = p.rows_per_group >= TM * 16 ? g0 + (grem + ro >= p.rows_per_group ? 1 : 0) : m / p.rows_per_group;
+                const float4 t0 = *reinterpret_cast<const float4*>(p.rowbias + (int64_t)grp * p.ldrb + n);
+                add[0] += t0.x; add[1] += t0.y; add[2] += t0.z; add[3] += t0.w;
+            }
+            float bz[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const float4 t0 = *reinterpret_cast<const float4*>(p.bias + n);
+                bz[0] = t0.x; bz[1] = t0.y; bz[2] = t0.z; bz[3] = t0.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs_f32
+            *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// split-K: sum the float32 partial slabs ws[s][m][n] in a fixed order, then the fused epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const GemmParams p) {
+    const int NC = (p.N + 3) / 4;
+    const int64_t total = (int64_t)p.M * NC;
+    const int64_t slab = (int64_t)p.M * p.N;
+    const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.residual == nullptr || p.ldr % 4 == 0) &&
+                     (p.rowbias == nullptr || (p.ldrb % 4 == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / NC), n = (int)(i - (int64_t)m * NC) * 4;
+        const int nvalid = p.N - n < 4 ? p.N - n : 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* src = p.ws + (int64_t)m * p.N + n;
+        for (int s = 0; s < p.ksplit; ++s, src += slab) {
+            if (nvalid == 4 && vec) {
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            } else {
+                for (int j = 0; j < nvalid; ++j) v[j] += src[j];
+            }
+        }
+        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ldrb : nullptr;
+        const float* res = p.residual ? (const float*)p.residual + (int64_t)m * p.ldr + n : nullptr;
+        float* o = (float*)p.C + (int64_t)m * p.ldc + n;
+        for (int j = 0; j < nvalid; ++j) {
+            float x = v[j] * p.alpha;
+            float add = 0.f;
+            if (p.bias) x += p.bias[n + j];
+            if (res) add += res[j];
+            if (rb) add += rb[n + j];
+            v[j] = apply_act(x + add, p.act);  // (acc*alpha + bias) + (residual + rowbias): the association of the tile epilogues
+        }
+        if (nvalid == 4 && vec) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int j = 0; j < nvalid; ++j) o[j] = v[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ring kernel: WM x WN waves, wave tile (TM*16) x (TN*16), NST-stage LDS ring filled by LDS-DMA with counted waits
+// ------------------------------------------------------------------------------------------------
+template <bool CONV, bool WSPLIT, int WM, int WN, int TM, int TN, int NST>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void gemm_split_kernel(const GemmParams p) {
+    constexpr int NWAVES = WM * WN;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int RPP = NWAVES * 8;                 // tile rows written per staging pass (8 rows per wave instruction)
+    constexpr int NA = (BM + RPP - 1) / RPP;        // A staging slots per thread
+    constexpr int NW = (BN + RPP - 1) / RPP;        // W staging slots per thread (the last may be invalid for some waves)
+    constexpr bool A_RAGGED = (BM % RPP) != 0, W_RAGGED = (BN % RPP) != 0;
+    constexpr int D = NST - 1;                      // prefetch distance in tiles
+    static_assert(!A_RAGGED && BN % 8 == 0 && NST >= 2 && NST <= 3, "bad ring geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kStage = (BM + BN) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WN, wc = wid % WN;
+    int m0, n0;
+    {   // XCD-aware tile order (gemm_ring_kernel)
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+        if (p.M >= p.N || CONV) {
+            const int mt = L / tiles_n;
+            m0 = mt * BM;
+            n0 = (L - mt * tiles_n) * BN;
+        } else {
+            const int nt = L / tiles_m;
+            n0 = nt * BN;
+            m0 = (L - nt * tiles_m) * BM;
+        }
+    }
+    const int z = p.ksplit > 1 ? 0 : blockIdx.z;
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    const int srow = tid >> 3;                                    // 0 .. RPP-1
+    const int chunk = (tid & 7) ^ ((srow >> 1) & 7);              // swizzled SOURCE chunk (RPP is a multiple of 16)
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+
+    unsigned aoff[NA], woff[NW];
+    int pb[NA], py[NA], px[NA];
+    bool pv[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + srow + RPP * i;
+        pv[i] = m < p.M;
+        pb[i] = py[i] = px[i] = 0;
+        if (CONV) {
+            if (pv[i]) {
+                const int hw = p.Hout * p.Wout;
+                if (((hw & (hw - 1)) | (p.Wout & (p.Wout - 1))) == 0) {
+                    const int sh = __builtin_ctz(hw), sw = __builtin_ctz(p.Wout);
+                    pb[i] = m >> sh;
+                    const int rem = m & (hw - 1);
+                    py[i] = rem >> sw;
+                    px[i] = rem & (p.Wout - 1);
+                } else {
+                    pb[i] = m / hw;
+                    const int rem = m - pb[i] * hw;
+                    py[i] = rem / p.Wout;
+                    px[i] = rem - py[i] * p.Wout;
+                }
+            }
+            aoff[i] = kOOB;
+        } else {
+            aoff[i] = pv[i] ? (unsigned)m * (unsigned)p.lda * 4u + (unsigned)chunk * 16u : kOOB;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int rl = srow + RPP * i;
+        const int n = n0 + rl;
+        woff[i] = (rl < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldw * 4u + (unsigned)chunk * 16u : kOOB;
+    }
+    const bool w_last = !W_RAGGED || ((NW - 1) * RPP + wuni * 8 < BN);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = p.K / BKS;
+    const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * per;
+    const int nk = (kt_begin + per <= nk_total ? per : nk_total - kt_begin);
+    int tap = 0, c0 = 0, cb0 = 0;
+    bool newtap = true;
+    if (CONV) {
+        const int sb = p.cblk / BKS, per_cb = 9 * sb;
+        const int cbi = kt_begin / per_cb, rem = kt_begin - cbi * per_cb;
+        tap = rem / sb;
+        cb0 = cbi * p.cblk;
+        c0 = cb0 + (rem - tap * sb) * BKS;
+    }
+
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    u32x4 dA, dW;
+    {
+        const uint64_t ba = (uint64_t)((const float*)p.A + (int64_t)z * p.sA), bw = (uint64_t)((const float*)p.W + (int64_t)z * p.sW);
+        dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+        dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+    }
+    auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                     :
+                     : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                     : "memory", "m0");
+#pragma clang diagnostic pop
+    };
+    auto dma_tile = [&](int kt, int stage_idx) {
+        unsigned kbytes = (unsigned)(kt_begin + kt) * (BKS * 4);
+        unsigned abytes = kbytes;
+        if (CONV) {
+            if (newtap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) aoff[i] = conv_tap_offset_f32(p, pv[i], pb[i], py[i], px[i], ky, kx, chunk);
+                newtap = false;
+            }
+            abytes = (unsigned)c0 * 4u;
+            kbytes = (unsigned)(tap * p.Cin + c0) * 4u;  // weights are [Cout][tap][Cin], 4 bytes per k in either layout
+        }
+        const unsigned stage = lds_base + (unsigned)stage_idx * kStage + (unsigned)wuni * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (RPP * 128), aoff[i], abytes);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (i + 1 < NW || w_last) dma16(dW, stage + BM * 128 + i * (RPP * 128), woff[i], kbytes);
+        }
+        if (CONV) {
+            c0 += BKS;
+            if (c0 >= cb0 + p.cblk) {
+                c0 = cb0;
+                ++tap;
+                newtap = true;
+                if (tap == 9) { tap = 0; cb0 += p.cblk; c0 = cb0; }
+            }
+        }
+    };
+    auto wait_tiles = [&](int ahead) {
+        if (ahead <= 0) { wait_vmcnt<0>(); return; }
+        if (w_last) {
+            if (ahead == 1) wait_vmcnt<NA + NW>();
+            else wait_vmcnt<2 * (NA + NW)>();
+        } else {
+            if (ahead == 1) wait_vmcnt<NA + NW - 1>();
+            else wait_vmcnt<2 * (NA + NW - 1)>();
+        }
+    };
+
+    const int frow = lane & 15, fq = lane >> 4;
+    auto compute = [&](int stage_idx) {
+        const unsigned char* sA = smem + stage_idx * kStage;
+        const unsigned char* sW = sA + BM * 128;
+        uint4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wr * (TM * 16) + i * 16 + frow;
+            const float4 x0 = *reinterpret_cast<const float4*>(sA + lds_off(row, fq));
+            const float4 x1 = *reinterpret_cast<const float4*>(sA + lds_off(row, 4 + fq));
+            split8(x0, x1, ah[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wc * (TN * 16) + j * 16 + frow;
+            if (WSPLIT) {
+                bh[j] = *reinterpret_cast<const uint4*>(sW + lds_off(row, fq));
+                bl[j] = *reinterpret_cast<const uint4*>(sW + lds_off(row, 4 + fq));
+            } else {
+                const float4 x0 = *reinterpret_cast<const float4*>(sW + lds_off(row, fq));
+                const float4 x1 = *reinterpret_cast<const float4*>(sW + lds_off(row, 4 + fq));
+                split8(x0, x1, bh[j], bl[j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = mfma_h(bl[j], ah[i], acc[i][j]);  // D[n][m]: lane = (m, 4 n's); small terms first
+                acc[i][j] = mfma_h(bh[j], al[i], acc[i][j]);
+                acc[i][j] = mfma_h(bh[j], ah[i], acc[i][j]);
+            }
+    };
+
+    if (nk > 0) {
+#pragma unroll
+        for (int t = 0; t < D; ++t)
+            if (t < nk) dma_tile(t, t);
+        int st_cur = 0, st_fill = D % NST;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int rem = nk - 1 - kt;
+            wait_tiles(rem < D - 1 ? rem : D - 1);
+            __syncthreads();
+            if (kt + D < nk) dma_tile(kt + D, st_fill);
+            compute(st_cur);
+            st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+            st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
+        }
+    }
+    const int mw = m0 + wr * (TM * 16), nw = n0 + wc * (TN * 16);
+    constexpr int kStrip = 32 * (TN * 16 + 4);  // floats per wave
+    constexpr bool strips_fit = (TM % 2 == 0) && ((size_t)NWAVES * kStrip * 4 <= (size_t)NST * kStage);
+    if constexpr (strips_fit) {
+        const bool full = m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0;
+        if (p.ksplit > 1 && full) {
+            __syncthreads();
+            epilogue_rows_f32<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, mw, nw, lane, z, ks);
+            return;
+        }
+        const bool rows_ok = p.ksplit <= 1 && full && (p.ldc & 3) == 0 && (p.sC & 3) == 0 &&
+                             (p.residual == nullptr || ((p.ldr & 3) == 0 && (p.sR & 3) == 0)) &&
+                             (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                             (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+        if (rows_ok) {
+            __syncthreads();  // every wave is done with the K-loop stages: the strips overwrite them
+            epilogue_rows_f32<TM, TN, false>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, mw, nw, lane, z, ks);
+            return;
+        }
+    }
+    epilogue_regs_f32<TM, TN>(p, acc, mw, nw, frow, fq, z, ks);
+}
+
+// one launch of the pre-split weight layout: out[n][kb][plane][q][j], plane 0 = hi, 1 = lo; chunk q holds
+// k = kb*32 + {4q..4q+3, 16+4q..16+4q+3}
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int64_t N, int64_t K, int64_t ldw) {
+    const int64_t nblk = K / 32, total = N * nblk * 4;  // one thread per (row, k block, chunk q)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3);
+        const int64_t blk = i >> 2, n = blk / nblk, kb = blk - n * nblk;
+        const float* src = w + n * ldw + kb * 32 + 4 * q;
+        const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 16);
+        uint4 hi, lo;
+        split8(x0, x1, hi, lo);
+        unsigned* dst = out + blk * 32 + q * 4;  // 128 bytes = 32 words per (row, k block)
+        *reinterpret_cast<uint4*>(dst) = hi;
+        *reinterpret_cast<uint4*>(dst + 16) = lo;
+    }
+}
+
+struct SplitPlan {
+    int bm, bn, ksplit;
+};
+
+// Tile / split-K selection: the 16-bit heuristic of gemm.hip (make_plan) in units of 64-deep K steps; the tiles are
+// 128 x 160 / 128 x 128 (two workgroups per CU) and 64 x 64 for launches that cannot put 256 large tiles on the chip.
+SplitPlan make_split_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
+    SplitPlan pl{64, 64, 1};
+    if (M >= 96 && N >= 96) {
+        pl.bm = 128;
+        pl.bn = (N % 160 == 0) ? 160 : 128;
+    }
+    const int64_t tiles = (int64_t)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn) * batch;
+    const int nk = K / 64;
+    if (batch == 1 && tiles < 160 && nk >= 24) {
+        int ks = (int)(((tiles >= 64 ? 512 : 256) + tiles / 2) / tiles);
+        if (ks > nk / 8) ks = nk / 8;
+        if (ks > 16) ks = 16;
+        if (ks > 1 && (int64_t)ks * M * N * (int64_t)sizeof(float) <= ws_bytes) pl.ksplit = ks;
+    }
+    if (batch == 1 && pl.bm == 128 && tiles >= 224 && tiles <= 256 && nk >= 160 && 2 * (int64_t)M * N * (int64_t)sizeof(float) <= ws_bytes)
+        pl.ksplit = 2;
+    if (pl.ksplit == 1 && batch > 1 && M <= 640 && pl.bm == 128) { pl.bm = 64; pl.bn = 64; }
+    if (pl.ksplit == 1 && tiles < 256 && pl.bm == 128) { pl.bm = 64; pl.bn = 64; }
+    return pl;
+}
+
+template <bool CONV, bool WSPLIT, int WM, int WN, int TM, int TN, int NST>
+hipError_t launch_split(const GemmParams& p, int gz, hipStream_t s) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
+    if (smem > 64 * 1024) {
+        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<CONV, WSPLIT, WM, WN, TM, TN, NST>), (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);
+    gemm_split_kernel<CONV, WSPLIT, WM, WN, TM, TN, NST><<<grid, WM * WN * 64, smem, s>>>(p);
+    return hipGetLastError();
+}
+
+template <bool CONV, bool WSPLIT>
+int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+    const SplitPlan pl = make_split_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0);
+    p.ksplit = pl.ksplit;
+    p.ws = (float*)ws;
+    const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
+    hipError_t e;
+    if (pl.bm == 128 && pl.bn == 160) e = launch_split<CONV, WSPLIT, 2, 2, 4, 5, 2>(p, gz, s);
+    else if (pl.bm == 128) e = launch_split<CONV, WSPLIT, 2, 2, 4, 4, 2>(p, gz, s);
+    else e = launch_split<CONV, WSPLIT, 2, 2, 2, 2, 2>(p, gz, s);
+    if (e == hipSuccess && pl.ksplit > 1) {
+        const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
+        int64_t g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        splitk_reduce_f32_kernel<<<(int)g, 256, 0, s>>>(p);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        gmd_set_error("%s: launch failed: %s", name, hipGetErrorString(e));
+        return GMD_ERR_LAUNCH;
+    }
+    return GMD_OK;
+}
+
+// channel block of the conv3x3 K order (conv_channel_block of gemm.hip with 4-byte elements and 32-channel steps)
+int split_channel_block(int B, int Hin, int Win, int Cin, int Cout) {
+    const int64_t rows_total = (int64_t)B * Hin * Win;
+    const int tiles_n = (Cout + 159) / 160;
+    const int64_t rows_resident = (int64_t)(64 / tiles_n > 0 ? 64 / tiles_n : 1) * 128;
+    const int64_t rows = rows_total / 8 < rows_resident ? (rows_total + 7) / 8 : rows_resident;
+    const int64_t budget = 3ll << 20;
+    if (rows * Cin * 4 <= budget) return Cin;
+    int best = 32;
+    for (int d = 32; d < Cin; d += 32)
+        if (Cin % d == 0 && rows * d * 4 <= budget) best = d;
+    return best;
+}
+
+}  // namespace
+
+// called by gmd_gemm_nt / gmd_conv3x3 (gemm.hip) for the two split dtype codes; the parameter block is validated there
+int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+    const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
+    return w_presplit ? launch_split_any<false, true>(p, batch, ws, ws_bytes, s, name) : launch_split_any<false, false>(p, batch, ws, ws_bytes, s, name);
+}
+int gmd_launch_split_conv(const void* params, int w_presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+    GemmParams p = *reinterpret_cast<const GemmParams*>(params);
+    p.cblk = split_channel_block(B, p.Hin, p.Win, p.Cin, p.N);
+    return w_presplit ? launch_split_any<true, true>(p, 1, ws, ws_bytes, s, name) : launch_split_any<true, false>(p, 1, ws, ws_bytes, s, name);
+}
+
+extern "C" int gmd_split_weights(const float* W, void* out, int64_t N, int64_t K, int64_t ldw, gmd_stream_t stream) {
+    GMD_REQUIRE(N >= 0 && K >= 0 && K % 32 == 0 && ldw >= K && ldw % 4 == 0, "gmd_split_weights: K=%lld must be a multiple of 32, ldw >= K a multiple of 4",
+                (long long)K);
+    if (N == 0 || K == 0) return GMD_OK;
+    GMD_REQUIRE(W && out && gmd_aligned16(W) && gmd_aligned16(out), "gmd_split_weights: null or unaligned pointer");
+    const int64_t total = N * (K / 32) * 4;
+    int64_t g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    split_weights_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(W, (unsigned*)out, N, K, ldw);
+    GMD_CHECK_LAUNCH("gmd_split_weights");
+    return GMD_OK;
+}

@@ -165,8 +165,8 @@ class AutoencoderKL(_HipModule):
             # to_out(P (V + 1 b_v^T)) = W_o P V + (W_o b_v + b_o)
             bo_f = (wo.double() @ bv.double() + bo.double()).float()
             return dict(r0=resnet(k + ".resnets.0"), r1=resnet(k + ".resnets.1"), gn=self._norm(a + ".group_norm"),
-                        qk=self._act(torch.cat([wq, wk], 0)), qkb=self._f32(torch.cat([bq, bk], 0)),
-                        v=self._act(wv), o=self._act(wo), ob=self._f32(bo_f))
+                        qk=self._wt(torch.cat([wq, wk], 0)), qkb=self._f32(torch.cat([bq, bk], 0)),
+                        v=self._wa(wv), o=self._wt(wo), ob=self._f32(bo_f))
 
         rev = list(reversed(list(c.block_out_channels)))
         # post_quant_conv (1x1, 4->4) folded into conv_in's padded input: done as its own tiny GEMM on padded channels
@@ -174,7 +174,7 @@ class AutoencoderKL(_HipModule):
         pq_w[: c.latent_channels, : c.latent_channels] = self._raw["post_quant_conv.weight"].reshape(c.latent_channels, -1)
         pq_b = torch.zeros(self._lc_pad)
         pq_b[: c.latent_channels] = self._raw["post_quant_conv.bias"]
-        w["pq"] = (self._act(pq_w), self._f32(pq_b))
+        w["pq"] = (self._wt(pq_w), self._f32(pq_b))
         w["d_in"] = self._conv3("decoder.conv_in", self._lc_pad)
         w["d_mid"] = mid("decoder.mid_block")
         w["d_up"] = []
@@ -190,7 +190,7 @@ class AutoencoderKL(_HipModule):
         t[: wo.shape[0]] = wo.permute(0, 2, 3, 1)
         bo = torch.zeros(4)
         bo[: wo.shape[0]] = self._raw["decoder.conv_out.bias"]
-        w["d_out"] = (self._act(t.reshape(4, -1)), self._f32(bo))
+        w["d_out"] = (self._wt(t.reshape(4, -1)), self._f32(bo))
         if self.with_encoder:
             ch = list(c.block_out_channels)
             self._img_pad = _pad_to(c.in_channels, kmul)

@@ -124,10 +124,10 @@ class CLIPTextModel(_HipModule):
             qkv_b = torch.cat([r[p + f"self_attn.{x}.bias"] for x in ("q_proj", "k_proj")])
             w["layers"].append(dict(
                 ln1=self._norm(p + "layer_norm1"), ln2=self._norm(p + "layer_norm2"),
-                qk=(self._act(qkv_w), self._f32(qkv_b)),                       # one GEMM -> [tokens, 2C] = [q | k]
-                v=self._act(r[p + "self_attn.v_proj.weight"]),
+                qk=(self._wt(qkv_w), self._f32(qkv_b)),                       # one GEMM -> [tokens, 2C] = [q | k]
+                v=self._wa(r[p + "self_attn.v_proj.weight"]),
                 # softmax rows sum to one, so the V bias passes through the attention unchanged: fold it into out_proj
-                out=(self._act(r[p + "self_attn.out_proj.weight"]),
+                out=(self._wt(r[p + "self_attn.out_proj.weight"]),
                      self._f32(r[p + "self_attn.out_proj.bias"] + r[p + "self_attn.out_proj.weight"] @ r[p + "self_attn.v_proj.bias"])),
                 fc1=self._lin(p + "mlp.fc1"), fc2=self._lin(p + "mlp.fc2")))
         return w

@@ -118,7 +118,8 @@ class _HipModule(ConfigMixin):
 
     # -- layout helpers --------------------------------------------------------------------------
     def _kmul(self):
-        return 64 if ops.is_half(self._dtype) else 16
+        """Channel multiple the convolution kernels need: 64 (16-bit), 32 (float32 on the matrix cores), 16 (exact float32)."""
+        return 64 if ops.is_half(self._dtype) else (32 if ops.f32_split() else 16)
 
     def _act(self, t):
         return t.to(self._device, self._dtype).contiguous()
@@ -126,18 +127,34 @@ class _HipModule(ConfigMixin):
     def _f32(self, t):
         return t.to(self._device, torch.float32).contiguous()
 
+    def _split_mode(self):
+        return self._dtype == torch.float32 and ops.f32_split()
+
+    def _wt(self, t):
+        """A weight that is the W operand of gemm_nt / conv3x3.  float32 on the matrix cores: scaled by a power of two and
+        split into float16 hi / lo once, here (hip_ops.split_weights)."""
+        w = self._act(t)
+        if self._split_mode() and w.dim() == 2 and w.shape[1] % 32 == 0:
+            return ops.split_weights(w)
+        return w
+
+    def _wa(self, t):
+        """A weight that is the A operand (V^T[b] = W_v x_b^T): plain float32, power-of-two scaled in split mode."""
+        w = self._act(t)
+        return ops.scale_weight(w) if self._split_mode() else w
+
     def _conv3(self, key, cin_pad=None):
         w = self._raw[key + ".weight"]  # [Cout, Cin, 3, 3]
         cout, cin = w.shape[0], w.shape[1]
         cin_pad = cin_pad or cin
         t = torch.zeros(cout, 3, 3, cin_pad)
         t[..., :cin] = w.permute(0, 2, 3, 1)
-        return self._act(t.reshape(cout, 9 * cin_pad)), self._f32(self._raw[key + ".bias"])
+        return self._wt(t.reshape(cout, 9 * cin_pad)), self._f32(self._raw[key + ".bias"])
 
     def _lin(self, key, bias=True):
         w = self._raw[key + ".weight"]
         w = w.reshape(w.shape[0], -1)  # Linear [out,in] or conv1x1 [out,in,1,1]
-        return self._act(w), (self._f32(self._raw[key + ".bias"]) if bias else None)
+        return self._wt(w), (self._f32(self._raw[key + ".bias"]) if bias else None)
 
     def _norm(self, key):
         return self._f32(self._raw[key + ".weight"]), self._f32(self._raw[key + ".bias"])
@@ -159,8 +176,10 @@ def composed_attention(q, q_col, ldq, k, k_col, ldk, vt, B, H, d, nq, nk, scale,
         ops.gemm_raw(q.data_ptr() + (b * nq * ldq + q_col) * es, k.data_ptr() + (b * nk * ldk + k_col) * es, s.data_ptr(),
                      dtype, torch.float32, nq, nk, d, ldq, ldk, nkp, batch=H, sA=d, sW=d, sC=nq * nkp)
         p = ops.softmax_rows(s, nk, scale, dtype, ldp=nkp, causal_nq=nq if causal else 0)
+        # float32: the probabilities (~1/nk) would lose their float16 lo half to the subnormal range in a split product, so
+        # this one stays on the exact kernel (small: the VAE mid block and the 77-token text encoder only)
         ops.gemm_raw(p.data_ptr(), vt.data_ptr() + b * H * d * ldvt * es, out.data_ptr() + b * nq * H * d * es,
-                     dtype, dtype, nq, d, nkp, nkp, ldvt, H * d, batch=H, sA=nq * nkp, sW=d * ldvt, sC=d)
+                     dtype, dtype, nq, d, nkp, nkp, ldvt, H * d, batch=H, sA=nq * nkp, sW=d * ldvt, sC=d, exact=True)
     return out
 
 
@@ -373,12 +392,12 @@ class UNet2DConditionModel(_HipModule):
             for nm in ("norm1", "norm2", "norm3"):
                 t[nm] = self._norm(f"{b}.{nm}")
             q1, k1 = self._raw[f"{b}.attn1.to_q.weight"], self._raw[f"{b}.attn1.to_k.weight"]
-            t["qk1"] = self._act(torch.cat([q1, k1], 0))  # fused [2C, C] projection
-            t["v1"] = self._lin(f"{b}.attn1.to_v", False)[0]
+            t["qk1"] = self._wt(torch.cat([q1, k1], 0))  # fused [2C, C] projection
+            t["v1"] = self._wa(self._raw[f"{b}.attn1.to_v.weight"])
             t["o1"] = self._lin(f"{b}.attn1.to_out.0")
             t["q2"] = self._lin(f"{b}.attn2.to_q", False)[0]
             t["k2"] = self._lin(f"{b}.attn2.to_k", False)[0]
-            t["v2"] = self._lin(f"{b}.attn2.to_v", False)[0]
+            t["v2"] = self._wa(self._raw[f"{b}.attn2.to_v.weight"])
             t["o2"] = self._lin(f"{b}.attn2.to_out.0")
             t["ff1"] = self._lin(f"{b}.ff.net.0.proj")
             if ops.is_half(self._dtype):
@@ -414,7 +433,7 @@ class UNet2DConditionModel(_HipModule):
         w["norm_out"] = self._norm("conv_norm_out")
         w["conv_out"] = self._conv3("conv_out")
         # all ResnetBlock2D.time_emb_proj layers as ONE [sum(Cout), 1280] GEMM per forward
-        w["te_all"] = (self._act(torch.cat(te_w, 0)), self._f32(torch.cat(te_b, 0)))
+        w["te_all"] = (self._wt(torch.cat(te_w, 0)), self._f32(torch.cat(te_b, 0)))
         self._kv_cache = {}
         self._graphs = {}
         self._t_dev = torch.zeros(1, dtype=torch.float32, device=self._device)
@@ -446,8 +465,8 @@ class UNet2DConditionModel(_HipModule):
         d = C // heads
         scale = d ** -0.5
         qk = ops.gemm_nt(n1, t["qk1"]).view(B, N, 2 * C)
-        if ops.is_half(self._dtype):
-            vt = ops.gemm_nt(t["v1"], n1.view(B, N, C), ldc=_pad_to(N, 8))  # V^T [B, C, N]
+        if ops.is_half(self._dtype) or ops.split_attention_ok(self._dtype, d):
+            vt = ops.gemm_nt(t["v1"], n1.view(B, N, C), ldc=_pad_to(N, 8 if ops.is_half(self._dtype) else 4))  # V^T [B, C, N]
             return ops.attention(qk, qk, vt, heads, N, scale, k_col=C)
         npad = _pad_to(N, 4)
         if npad != N:
@@ -522,7 +541,7 @@ class UNet2DConditionModel(_HipModule):
             B *= 2
         kc, vtc = self._cross_kv(t, ehs)
         L = ehs.shape[1]
-        if ops.is_half(self._dtype):
+        if ops.is_half(self._dtype) or ops.split_attention_ok(self._dtype, d):
             o = ops.attention(q, kc, vtc, heads, L, d ** -0.5)
         else:
             o = composed_attention(q, 0, C, kc, 0, C, vtc, B, heads, d, N, L, d ** -0.5, self._dtype)

@@ -12,15 +12,16 @@ float32 (parity path); biases / norm parameters / statistics are float32.
 """
 from __future__ import annotations
 
+import math
 import os
 
 import torch
 
 from . import profiling
-from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F16, GMD_F32, HipExtensionError, check, lib
+from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F16, GMD_F32, GMD_F32S, GMD_F32SW, HipExtensionError, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows",
+    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows", "set_f32_mode", "f32_split", "split_weights", "scale_weight", "split_attention_ok",
     "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "groupnorm_split", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
@@ -38,6 +39,71 @@ def dtype_code(dt):
 
 
 HALF_DTYPES = (torch.bfloat16, torch.float16)
+
+# How float32 contractions (gemm_nt, conv3x3, attention) run:
+#   "split" (default): on the matrix cores, every float32 operand taken as f16 hi + f16 lo and each product formed as three
+#            float16 MFMA passes with float32 accumulation (GMD_F32S / GMD_F32SW, csrc/gemm_split.hip): float32-grade results
+#            (~2^-22 relative per term) at matrix-core speed -- the reference's own float32 numerics
+#            (scripts/inference/experiments/formal_improved.py:199), the path that meets the 1e-3 latent-RMS gate;
+#   "exact": the float32 FMA kernels on the vector units (bit-for-bit an fp32 FMA chain, ~12x slower end to end).
+F32_MODE = os.environ.get("GMD_F32_MODE", "split")
+if F32_MODE not in ("split", "exact"):
+    raise HipExtensionError(f"GMD_F32_MODE={F32_MODE!r}: expected 'split' or 'exact'")
+
+
+def set_f32_mode(mode):
+    """Switch float32 contractions between "split" (matrix cores, three float16 products) and "exact" (vector FMA).
+    Models prepare their weights for the mode that is active when they are placed on the device."""
+    global F32_MODE
+    if mode not in ("split", "exact"):
+        raise HipExtensionError("f32 mode must be 'split' or 'exact'")
+    prev, F32_MODE = F32_MODE, mode
+    return prev
+
+
+def f32_split():
+    return F32_MODE == "split"
+
+
+def split_weights(w):
+    """float32 [N, K] (K % 32 == 0) -> the pre-split hi/lo float16 layout of gmd_split_weights, held in a float32 tensor of
+    the same shape (same byte count) that is marked ``_split``: gemm_nt / conv3x3 then take it as the GMD_F32SW W operand."""
+    _dev(w)
+    _f32(w, "split_weights input")
+    if w.dim() != 2 or w.shape[1] % 32:
+        raise HipExtensionError("split_weights: [N, K] with K a multiple of 32")
+    ws = scale_weight(w)
+    out = torch.empty_like(w)
+    check(lib().gmd_split_weights(_ptr(ws), _ptr(out), w.shape[0], w.shape[1], w.shape[1], _stream()), "gmd_split_weights")
+    out._split = True
+    out._alpha = ws._alpha
+    return out
+
+
+def scale_weight(w):
+    """``w * 2^s`` with the largest magnitude brought into [2^12, 2^13), marked ``_alpha = 2^-s`` (gemm_nt / conv3x3 fold it
+    into their alpha).  The lo half of a split operand is a float16 of ~2^-11 of the value: for typical weight magnitudes
+    (1e-2) it would sit in float16's subnormal range and lose most of its bits; scaled, every weight down to 2^-15 of the
+    largest keeps a full 11-bit lo.  A power of two, so the scaling itself is exact.  Weight preparation only (reads the
+    maximum back to the host)."""
+    _dev(w)
+    _f32(w, "scale_weight input")
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    s = 0 if amax == 0.0 or not math.isfinite(amax) else max(-60, min(60, 13 - math.frexp(amax)[1]))
+    out = w * (2.0 ** s) if s else w.clone()
+    out._alpha = 2.0 ** -s
+    return out
+
+
+def _contract_code(a, w, K):
+    """dtype code of a contraction of ``a`` with the W operand ``w`` over K."""
+    if a.dtype != torch.float32:
+        if getattr(w, "_split", False):
+            raise HipExtensionError("a pre-split float32 weight met a 16-bit activation")
+        return dtype_code(a.dtype)
+    if getattr(w, "_split", False):
+        return GMD_F32SW
+    return GMD_F32S if (F32_MODE == "split" and K % 32 == 0) else GMD_F32
 
 
 def is_half(dt):
@@ -172,7 +238,6 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     rb_ptr, rb_ld = _rowbias(rowbias)
     if a.dtype != w.dtype:
         raise HipExtensionError(f"gemm_nt: dtype mismatch {a.dtype} vs {w.dtype}")
-    dt = dtype_code(a.dtype)
     batch = 1
     if a.dim() == 3 or w.dim() == 3:
         batch = a.shape[0] if a.dim() == 3 else w.shape[0]
@@ -180,6 +245,10 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     N = w.shape[-2]
     if w.shape[-1] != K:
         raise HipExtensionError(f"gemm_nt: K mismatch {a.shape} vs {w.shape}")
+    dt = _contract_code(a, w, K)
+    if getattr(a, "_split", False):
+        raise HipExtensionError("gemm_nt: a pre-split weight can only be the W operand")
+    alpha = float(alpha) * getattr(a, "_alpha", 1.0) * getattr(w, "_alpha", 1.0)  # weights stored scaled by a power of two
     sA = M * K if a.dim() == 3 else 0
     sW = N * K if w.dim() == 3 else 0
     out_dtype = out_dtype or a.dtype
@@ -211,6 +280,8 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
         tm.end("gemm_nt", 2.0 * batch * M * N * K, batch * (M * K + N * K + M * N) * es, t0)
     if st is not None:
         out._colstats = (st, N)
+    elif getattr(out, "_colstats", None) is not None:  # a reused `out=` buffer must not keep an earlier producer's statistics
+        del out._colstats
     return out
 
 
@@ -239,9 +310,9 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("conv3x3") else None
     t0 = tm.begin() if tm else None
-    check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), dtype_code(x.dtype), dtype_code(out_dtype), B, H, W, cin, cout,
+    check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), _contract_code(x, w, cin), dtype_code(out_dtype), B, H, W, cin, cout,
                             stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), rb_ptr, rb_ld,
-                            _ptr(residual), _ptr(st), COLSTATS_BUCKET if st is not None else 0,
+                            _ptr(residual), float(getattr(w, "_alpha", 1.0)), _ptr(st), COLSTATS_BUCKET if st is not None else 0,
                             _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_conv3x3")
     if tm:
         tm.end("conv3x3", 2.0 * B * ho * wo * cout * 9 * cin, x.numel() * x.element_size() + w.numel() * w.element_size()
@@ -249,6 +320,14 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     if st is not None:
         y._colstats = (st, cout)
     return y, ho, wo
+
+
+SPLIT_ATTENTION_HEAD_DIMS = (40, 80, 160)  # float32 flash kernel (attention_split.hip): the UNet's head dims
+
+
+def split_attention_ok(dtype, d):
+    """True when ``attention`` takes float32 tensors of this head dim (F32_MODE 'split')."""
+    return dtype == torch.float32 and f32_split() and d in SPLIT_ATTENTION_HEAD_DIMS
 
 
 def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False):
@@ -262,14 +341,21 @@ def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False):
     if k.shape[1] < nk or vt.shape[2] < nk or k_col + hd > ldk or hd > ldq:
         raise HipExtensionError("attention: operand shapes inconsistent")
     o = torch.empty((B, nq, hd), dtype=q.dtype, device=q.device)
+    if q.dtype == torch.float32:
+        if not (f32_split() and d in SPLIT_ATTENTION_HEAD_DIMS):
+            raise HipExtensionError("attention: float32 runs on the split (three float16 products) kernel, head dims 40/80/160, "
+                                    "in F32_MODE 'split' only; the exact float32 path composes gemm_nt + softmax_rows")
+        code = GMD_F32S
+    else:
+        code = dtype_code(q.dtype)
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("attention") else None
     t0 = tm.begin() if tm else None
-    check(lib().gmd_attention(_ptr(q), _ptr(k) + k_col * k.element_size(), _ptr(vt), _ptr(o), dtype_code(q.dtype), B, heads, d,
+    check(lib().gmd_attention(_ptr(q), _ptr(k) + k_col * k.element_size(), _ptr(vt), _ptr(o), code, B, heads, d,
                               nq, nk, ldq, ldk, vt.shape[2], hd, nq * ldq, k.shape[1] * ldk, hd * vt.shape[2], nq * hd,
                               float(scale), int(bool(causal)), _stream()), "gmd_attention")
     if tm:  # QK^T + PV, algorithmic head dim (padding not counted)
-        tm.end("attention", 4.0 * B * nq * nk * hd, (2 * B * nq * hd + 2 * B * nk * hd) * 2, t0)
+        tm.end("attention", 4.0 * B * nq * nk * hd, (2 * B * nq * hd + 2 * B * nk * hd) * q.element_size(), t0)
     return o
 
 
@@ -627,11 +713,12 @@ def quantize_u8(x):
 
 
 def gemm_raw(a_ptr, w_ptr, c_ptr, dtype, out_dtype, M, N, K, lda, ldw, ldc, batch=1, sA=0, sW=0, sC=0,
-             bias=None, alpha=1.0, act=ACT_NONE):
+             bias=None, alpha=1.0, act=ACT_NONE, exact=False):
     """Pointer-level gmd_gemm_nt for strided sub-blocks (per-head attention products of the parity path).
     a_ptr/w_ptr/c_ptr are integer device addresses; the caller keeps the owning tensors alive."""
     _dev(bias)
-    check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, dtype_code(dtype), dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
+    code = GMD_F32S if (dtype == torch.float32 and F32_MODE == "split" and K % 32 == 0 and not exact) else dtype_code(dtype)
+    check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, code, dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
                             sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, 0, None, 0, 0, float(alpha), act, None, 0, None, 0, _stream()),
           "gmd_gemm_nt")
 

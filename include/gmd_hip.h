@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 5
+#define GMD_ABI_VERSION 6
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -40,6 +40,13 @@ extern "C" {
 #define GMD_F32 0
 #define GMD_BF16 1
 #define GMD_F16 2  /* IEEE half: same kernels and layouts as GMD_BF16, float16 elements / MFMA forms */
+/* float32 tensors whose contraction runs on the matrix cores as three float16 products (x = hi + lo, hi = f16(x),
+ * lo = f16(x - hi); a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with float32 accumulation: ~2^-22 relative per term, the order
+ * of float32 rounding; operands must stay inside the float16 range, |x| <= 65504).  Accepted by gmd_gemm_nt, gmd_conv3x3
+ * and gmd_attention only; every other entry point takes the same tensors as GMD_F32.  The reference runs its dual-UNet
+ * pipeline in float32 (scripts/inference/experiments/formal_improved.py:199): this is that precision at matrix-core speed. */
+#define GMD_F32S 3  /* both operands plain float32, split in the kernel */
+#define GMD_F32SW 4 /* W operand pre-split by gmd_split_weights (weights: split once when a model is placed on the device) */
 
 /* epilogue activation for gmd_gemm_nt */
 #define GMD_ACT_NONE 0
@@ -175,7 +182,8 @@ int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit);
  * A: [M,K] ld lda; W: [N,K] ld ldw (both K-contiguous); C: [M,N] ld ldc, out_dtype F32 or `dtype`.
  * bias: float32 [N] or NULL.  rowbias: float32 [ceil(M/rows_per_group), ldrb] (ldrb >= N; 0 means N) or NULL, added to rows
  * of group m/rows_per_group (ResnetBlock2D time-embedding add).  residual: `dtype` [M,N] ld ldr or NULL.
- * Requirements: K % 64 == 0 (BF16) / K % 4 == 0 (F32); lda, ldw multiples of 8 (BF16) / 4 (F32) elements;
+ * Requirements: K % 64 == 0 (BF16 / F16), K % 32 == 0 (F32S / F32SW), K % 4 == 0 (F32); lda, ldw multiples of 8 (16-bit) /
+ * 4 (float32) elements (ldw of a pre-split W counts k's, as for the plain matrix);
  * base pointers 16-byte aligned.  nn.Linear / conv1x1 / attention score products.
  * workspace (optional, float32 scratch of workspace_bytes): lets launches that cannot fill the chip split K
  * (deterministic slab reduction, no atomics); with NULL / too small a workspace K is not split. */
@@ -186,6 +194,12 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 const void* residual, int64_t ldr, int64_t strideR,
                 float alpha, int act, float* colstats, int colstats_bucket,
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
+
+/* Pre-split layout of a float32 weight matrix W [N,K] (row stride ldw, K % 32 == 0) for GMD_F32SW: `out` holds N*K*4 bytes,
+ * per row n and block of 32 k's 64 bytes of float16 hi followed by 64 bytes of float16 lo, each as four 16-byte chunks
+ * q = 0..3 holding k = {4q..4q+3, 16+4q..16+4q+3} of the block (the k's one MFMA lane group consumes).  For a convolution
+ * weight [Cout, 9*Cin] (k = tap*Cin + c, Cin % 32 == 0) the same call applies with K = 9*Cin. */
+int gmd_split_weights(const float* W, void* out, int64_t N, int64_t K, int64_t ldw, gmd_stream_t stream);
 
 /* Column statistics for a following GroupNorm (diffusers GroupNorm over a ResnetBlock2D / Transformer2DModel input: the
  * statistics pass is folded into the epilogue of the launch that produces the tensor).  With `colstats` non-NULL,
@@ -202,10 +216,11 @@ int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t wo
  * stride 1 or 2 (Downsample2D: Hout = (Hin+2-3)/2+1); upsample=1 fuses nearest-2x
  * (Upsample2D: conv over the virtual 2Hin x 2Win image).  pad_mode 0: symmetric padding 1;
  * pad_mode 1: pad (0,1,0,1) then stride 2 (VAE encoder Downsample2D(padding=0)).
- * Epilogue as gmd_gemm_nt (rowbias is [B, ldrb], one row per sample).  Cin % 64 == 0 (BF16) / % 16 (F32). */
+ * Epilogue as gmd_gemm_nt (rowbias is [B, ldrb], one row per sample; alpha scales the
+ * accumulated sum before the bias: 1 for a plain convolution, 2^-s for a weight that was stored scaled by 2^s).  Cin % 64 == 0 (BF16 / F16), % 32 (F32S / F32SW), % 16 (F32). */
 int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype,
                 int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode,
-                const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
+                const float* bias, const float* rowbias, int64_t ldrb, const void* residual, float alpha,
                 float* colstats, int colstats_bucket,
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
 

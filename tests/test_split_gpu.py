@@ -1,0 +1,307 @@
+"""float32 contractions on the matrix cores (GMD_F32S / GMD_F32SW: three float16 products per float32 product,
+csrc/gemm_split.hip, the float32 attention of csrc/attention_split.hip) against float64 references, against the exact
+float32 FMA kernels, and pre-split weights against the in-kernel split (bit for bit)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from gm_diffusion import hip_ops
+
+    return hip_ops
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(autouse=True)
+def split_mode():
+    o = ops()
+    prev = o.set_f32_mode("split")
+    yield
+    o.set_f32_mode(prev)
+
+
+# float32-grade: an exact fp32 FMA chain over K = 320..5120 terms sits at 1e-7..4e-7 relative to float64; the split path
+# adds ~2^-22 per term (random signs): the bound below is 3x the exact kernel's own error at the deepest K.
+TOL = 1.5e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (128, 128, 64), (300, 200, 320), (8, 1280, 1280), (616, 320, 768), (4096, 320, 320),
+                                   (2048, 2560, 320), (33, 4, 128), (70, 1000, 96), (1024, 1280, 5120), (256, 320, 5120), (2048, 640, 10240)])
+def test_split_gemm_vs_float64(M, N, K):
+    o = ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t()
+    ad, wd = a.to(DEV), w.to(DEV)
+    got = o.gemm_nt(ad, wd)  # both operands split in the kernel, W unscaled (magnitude 1/sqrt(K): its lo half is partly subnormal)
+    assert got.dtype == torch.float32 and rel_err(got, ref) < 3e-6, "plain"
+    o.set_f32_mode("exact")
+    e_exact = rel_err(o.gemm_nt(ad, wd), ref)  # the fp32 FMA chain's own distance from float64 (grows with K)
+    o.set_f32_mode("split")
+    ws = o.split_weights(wd)  # the product path: weight scaled by a power of two, split once
+    got_w = o.gemm_nt(ad, ws)
+    assert rel_err(got_w, ref) < max(4e-7, 1.5 * e_exact), "pre-split: no worse than 1.5x the exact float32 kernel"
+    assert torch.equal(got_w, o.gemm_nt(ad, o.scale_weight(wd))), "pre-split weights must give the in-kernel split's bits"
+    got = o.gemm_nt(ad, ws, bias=bias.to(DEV), residual=res.to(DEV), alpha=0.5)
+    assert rel_err(got, 0.5 * ref + bias.double() + res.double()) < TOL, "bias+residual"
+    got = o.gemm_nt(ad, ws, bias=bias.to(DEV), act=o.ACT_SILU)
+    assert rel_err(got, F.silu(ref + bias.double())) < TOL, "silu"
+    rpg = 7
+    rb = torch.randn((M + rpg - 1) // rpg, N, generator=g)
+    got = o.gemm_nt(ad, wd, rowbias=rb.to(DEV), rows_per_group=rpg)
+    assert rel_err(got, ref + rb.double().repeat_interleave(rpg, 0)[:M]) < TOL, "rowbias"
+
+
+def test_split_accuracy_is_float32_grade_not_float16_grade():
+    """The same product with operands rounded to float16 once (the float16 path's arithmetic) is ~500x further from float64."""
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    a, w = torch.randn(512, 1280, generator=g), torch.randn(640, 1280, generator=g) / 36.0
+    ref = a.double() @ w.double().t()
+    got = o.gemm_nt(a.to(DEV), w.to(DEV))
+    half = a.half().double() @ w.half().double().t()
+    e_split, e_half = rel_err(got, ref), rel_err(half, ref)
+    assert e_split < 1e-6 and e_half > 100 * e_split, (e_split, e_half)
+    e_scaled = rel_err(o.gemm_nt(a.to(DEV), o.split_weights(w.to(DEV))), ref)
+    assert e_scaled < 4e-7, e_scaled
+
+
+def test_split_small_weights_keep_their_precision_through_the_power_of_two_scale():
+    """The lo half of a split operand is a float16 of ~2^-11 of the value: for weights of magnitude 1e-3 it would fall into
+    float16's subnormal range and lose its bits.  split_weights / scale_weight store the weight scaled by a power of two
+    (exact) and fold the inverse into alpha: the result must not depend on the weight's scale."""
+    o = ops()
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(256, 640, generator=g) * torch.logspace(-2, 1, 640)[None, :]
+    w = torch.randn(320, 640, generator=g)
+    ref = a.double() @ w.double().t()
+    ad = a.to(DEV)
+    for scale in (1.0, 0.02, 2.0 ** -12, 300.0):
+        wd = (w * scale).to(DEV)
+        got = o.gemm_nt(ad, o.split_weights(wd))
+        assert rel_err(got, ref * scale) < 5e-7, scale
+        vt = o.gemm_nt(o.scale_weight(wd), ad)  # weight as the A operand (V^T = W_v x^T)
+        assert rel_err(vt, (ref * scale).t()) < 5e-7, scale
+    tiny = o.gemm_nt(ad, (w * 2.0 ** -12).to(DEV))  # unscaled tiny weights: still far better than float16, but not float32-grade
+    assert 5e-7 < rel_err(tiny, ref * 2.0 ** -12) < 1e-4
+
+
+def test_split_batched_and_swapped():
+    o = ops()
+    g = torch.Generator().manual_seed(9)
+    Bn, N, C = 3, 72, 128
+    x = torch.randn(Bn, N, C, generator=g)
+    wv = torch.randn(C, C, generator=g) / math.sqrt(C)
+    ld = 80
+    vt = o.gemm_nt(wv.to(DEV), x.to(DEV), ldc=ld)  # V^T[b] = W_v @ x[b]^T: both operands plain float32
+    ref = torch.einsum("ck,bnk->bcn", wv.double(), x.double())
+    assert vt.shape == (Bn, C, ld) and rel_err(vt[:, :, :N], ref) < TOL
+    y = o.gemm_nt(x.to(DEV), torch.stack([wv, wv * 2, wv * 3]).to(DEV))
+    ref2 = torch.stack([x[i].double() @ (wv.double() * (i + 1)).t() for i in range(3)])
+    assert rel_err(y, ref2) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [
+    (2, 8, 8, 64, 64, "s1"), (1, 16, 12, 128, 320, "s1"), (2, 8, 8, 32, 128, "s2"), (1, 9, 7, 64, 64, "s2"),
+    (2, 4, 6, 96, 64, "up"), (1, 8, 8, 64, 64, "pad1"), (1, 7, 9, 32, 64, "pad1"), (1, 64, 64, 320, 320, "s1"),
+    (2, 8, 8, 64, 4, "s1"), (8, 8, 8, 1280, 1280, "s1"), (2, 32, 32, 1280, 640, "s1"), (2, 64, 64, 640, 320, "s1"),
+])
+def test_split_conv3x3_vs_float64(B, H, W, Cin, Cout, mode):
+    o = ops()
+    g = torch.Generator().manual_seed(H * W + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g)
+    xd, wd = x.double(), w.double()
+    if mode == "s1":
+        ref, kw = F.conv2d(xd, wd, bias.double(), padding=1), {}
+    elif mode == "s2":
+        ref, kw = F.conv2d(xd, wd, bias.double(), stride=2, padding=1), dict(stride=2)
+    elif mode == "up":
+        ref, kw = F.conv2d(F.interpolate(xd, scale_factor=2.0, mode="nearest"), wd, bias.double(), padding=1), dict(upsample=True)
+    else:
+        ref, kw = F.conv2d(F.pad(xd, (0, 1, 0, 1)), wd, bias.double(), stride=2, padding=0), dict(stride=2, pad_mode=1)
+    Ho, Wo = ref.shape[-2:]
+    xl = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous().to(DEV)
+    wl = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(DEV)
+    tb = torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Ho * Wo, Cout, generator=g)
+    full = (ref + tb.double()[:, :, None, None]).permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout) + res.double()
+    y, ho, wo = o.conv3x3(xl, wl, B, H, W, bias=bias.to(DEV), rowbias=tb.to(DEV), residual=res.to(DEV), **kw)
+    assert (ho, wo) == (Ho, Wo) and rel_err(y, full) < TOL
+    y2, _, _ = o.conv3x3(xl, o.split_weights(wl), B, H, W, bias=bias.to(DEV), rowbias=tb.to(DEV), residual=res.to(DEV), **kw)
+    assert rel_err(y2, full) < 5e-7
+    y3, _, _ = o.conv3x3(xl, o.scale_weight(wl), B, H, W, bias=bias.to(DEV), rowbias=tb.to(DEV), residual=res.to(DEV), **kw)
+    assert torch.equal(y3, y2), "pre-split conv weights must give the in-kernel split's bits"
+
+
+def test_split_epilogue_fuzz():
+    """Seeded sweep over shapes that straddle every epilogue path of the split kernels (row-contiguous LDS epilogue on full
+    tiles, register epilogue on ragged edges, split-K slabs, 64x64 tiles) with all combinations of bias / row bias /
+    residual / activation / alpha."""
+    o = ops()
+    rng = np.random.default_rng(31)
+    g = torch.Generator().manual_seed(31)
+    acts = [(o.ACT_NONE, lambda z: z), (o.ACT_SILU, F.silu), (o.ACT_QUICK_GELU, lambda z: z * torch.sigmoid(1.702 * z))]
+    cases = 0
+    for _ in range(36):
+        M = int(rng.choice([128, 256, 384, 640, 1000, 1024, 2048, 4096, 16384]))
+        N = int(rng.choice([64, 128, 160, 320, 328, 640, 1280]))
+        K = int(rng.choice([32, 96, 320, 640, 1536, 2560]))
+        if M * N * K > 16384 * 640 * 640:
+            continue
+        use_bias, use_rb, use_res, presplit = (bool(v) for v in rng.integers(0, 2, 4))
+        act, fn = acts[int(rng.integers(0, 3))]
+        alpha = float(rng.choice([1.0, 0.5]))
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        ref = alpha * (a.double() @ w.double().t())
+        kw = {}
+        if use_bias:
+            b = torch.randn(N, generator=g)
+            kw["bias"] = b.to(DEV)
+            ref = ref + b.double()
+        if use_rb:
+            rpg = int(rng.choice([16, 48, 64, 100, 256, M]))
+            rb = torch.randn((M + rpg - 1) // rpg, N, generator=g)
+            kw.update(rowbias=rb.to(DEV), rows_per_group=rpg)
+            ref = ref + rb.double().repeat_interleave(rpg, 0)[:M]
+        if use_res:
+            r = torch.randn(M, N, generator=g)
+            kw["residual"] = r.to(DEV)
+            ref = ref + r.double()
+        wd = w.to(DEV)
+        got = o.gemm_nt(a.to(DEV), o.split_weights(wd) if presplit else wd, alpha=alpha, act=act, **kw)
+        assert got.shape == (M, N)
+        assert rel_err(got, fn(ref)) < TOL, (M, N, K, use_bias, use_rb, use_res, act, alpha, presplit)
+        cases += 1
+    assert cases >= 28
+
+
+def test_split_rejects_what_it_cannot_do():
+    o = ops()
+    a = torch.randn(64, 48, device=DEV)
+    w = torch.randn(64, 48, device=DEV)
+    y = o.gemm_nt(a, w)  # K % 32 != 0: the exact kernel takes it
+    assert rel_err(y, a.double() @ w.double().t()) < 2e-6
+    with pytest.raises(o.HipExtensionError):
+        o.split_weights(w)
+    ws = o.split_weights(torch.randn(64, 64, device=DEV))
+    with pytest.raises(o.HipExtensionError):
+        o.gemm_nt(ws, torch.randn(64, 64, device=DEV))  # a pre-split weight is a W operand only
+    with pytest.raises(o.HipExtensionError):
+        o.gemm_nt(torch.randn(64, 64, device=DEV).half(), ws)
+
+
+# ---------------------------------------------------------------------------------------------
+# float32 attention (attention_split.hip)
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, heads, scale):
+    B, Nq, C = q.shape
+    d = C // heads
+    qh = q.double().view(B, Nq, heads, d).transpose(1, 2)
+    kh = k.double().view(B, -1, heads, d).transpose(1, 2)
+    vh = v.double().view(B, -1, heads, d).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+def _vt(v, ld):
+    B, Nk, C = v.shape
+    out = torch.zeros(B, C, ld)
+    out[:, :, :Nk] = v.transpose(1, 2)
+    return out
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+@pytest.mark.parametrize("Nq,Nk", [(256, 256), (64, 77), (16, 16), (200, 130), (1024, 1024), (4096, 77)])
+def test_split_attention_vs_float64(D, Nq, Nk):
+    o = ops()
+    H, B = 2, 2
+    g = torch.Generator().manual_seed(D + Nq + Nk)
+    q = torch.randn(B, Nq, H * D, generator=g)
+    k = torch.randn(B, Nk, H * D, generator=g)
+    v = torch.randn(B, Nk, H * D, generator=g)
+    scale = D ** -0.5
+    ref = _attn_ref(q, k, v, H, scale)
+    ld = (Nk + 3) // 4 * 4
+    got = o.attention(q.to(DEV), k.to(DEV), _vt(v, ld).to(DEV), H, Nk, scale)
+    assert got.dtype == torch.float32 and rel_err(got, ref) < 1e-6, rel_err(got, ref)
+
+
+def test_split_attention_fused_qk_buffer_poisoned_padding_and_sharp_rows():
+    """Q and K as column ranges of one fused projection buffer; NaN-poisoned V^T row padding beyond Nk (ldvt > Nk) must never
+    reach the output; logits large enough that single keys dominate (rescale branch of the online softmax), all negative
+    logits, and one spiked key per row."""
+    o = ops()
+    H, D, B, N = 8, 40, 2, 333
+    C = H * D
+    g = torch.Generator().manual_seed(77)
+    qk = torch.randn(B, N, 2 * C, generator=g)
+    v = torch.randn(B, N, C, generator=g)
+    ld = 336 + 8
+    vt = _vt(v, ld)
+    vt[:, :, N:] = float("nan")
+    for mul in (1.0, 6.0, 25.0):
+        x = qk.clone()
+        x[:, :, :C] *= mul
+        ref = _attn_ref(x[:, :, :C], x[:, :, C:], v, H, D ** -0.5)
+        got = o.attention(x.to(DEV), x.to(DEV), vt.to(DEV), H, N, D ** -0.5, k_col=C)
+        assert torch.isfinite(got).all() and rel_err(got, ref) < 1e-6, mul
+    x = qk.clone()
+    x[:, :, C:] = -x[:, :, :C].abs() * 3  # all logits strongly negative
+    x[:, :, :C] = x[:, :, :C].abs()
+    x[:, 200, C:] = 4.0                   # ... except one key that every query prefers, late in the sequence
+    ref = _attn_ref(x[:, :, :C], x[:, :, C:], v, H, D ** -0.5)
+    got = o.attention(x.to(DEV), x.to(DEV), vt.to(DEV), H, N, D ** -0.5, k_col=C)
+    assert rel_err(got, ref) < 1e-6
+
+
+def test_split_attention_full_size_properties():
+    """4096 tokens (512^2), 8 heads of 40: rows of ones for V == 1, linear in V, invariant to the key order."""
+    o = ops()
+    H, D, B, N = 8, 40, 2, 4096
+    C = H * D
+    g = torch.Generator().manual_seed(3)
+    qk = (torch.randn(B, N, 2 * C, generator=g)).to(DEV)
+    v = torch.randn(B, N, C, generator=g)
+    ones = o.attention(qk, qk, torch.ones(B, C, N, device=DEV), H, N, D ** -0.5, k_col=C)
+    assert float((ones - 1).abs().max()) < 4e-6  # 4096-term float32 row sums
+    vt = v.transpose(1, 2).contiguous().to(DEV)
+    o1 = o.attention(qk, qk, vt, H, N, D ** -0.5, k_col=C)
+    o2 = o.attention(qk, qk, (2 * vt + 1).contiguous(), H, N, D ** -0.5, k_col=C)
+    assert rel_err(o2, 2 * o1 + 1) < 1e-6
+    perm = torch.randperm(N, generator=g).to(DEV)
+    kperm = qk.clone()
+    kperm[:, :, C:] = qk[:, perm, C:]
+    o3 = o.attention(qk, kperm, vt[:, :, perm].contiguous(), H, N, D ** -0.5, k_col=C)
+    assert rel_err(o3, o1) < 3e-6  # two summation orders of 4096 mostly cancelling terms (|o| ~ 0.02 |v|)
+    # against the exact composition on one (batch, head)
+    ref = _attn_ref(qk[:1, :, :D].cpu(), qk[:1, :, C:C + D].cpu(), v[:1, :, :D], 1, D ** -0.5)
+    assert rel_err(o1[:1, :, :D], ref) < 1e-6
+
+
+def test_split_attention_rejects_other_modes():
+    o = ops()
+    q = torch.randn(1, 64, 64, device=DEV)
+    with pytest.raises(o.HipExtensionError):
+        o.attention(q, q, torch.randn(1, 64, 64, device=DEV), 1, 64, 0.125)  # head dim 64 is not instantiated for float32
+    o.set_f32_mode("exact")
+    q = torch.randn(1, 64, 80, device=DEV)
+    with pytest.raises(o.HipExtensionError):
+        o.attention(q, q, torch.randn(1, 80, 64, device=DEV), 2, 64, 0.15)
