@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="run the GM UNet on the SDR stream instead of a second HIP stream")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying captured HIP graphs")
     ap.add_argument("--no-drift", action="store_true", help="skip the short bf16-vs-float32 drift measurement")
+    ap.add_argument("--no-tolerance-path", action="store_true",
+                    help="skip timing the float32 (three float16 MFMA passes) pipeline -- the path inside the 1e-3 gate -- beside the headline")
+    ap.add_argument("--tolerance-steps", type=int, default=1, help="timed full-workload steps of the tolerance path")
     ap.add_argument("--drift-steps", type=int, default=10)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (a 1-GPU box owns 16 cores)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
@@ -268,33 +271,83 @@ def main():
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(out["hdr"]).all().item())
 
-    # bf16 drift against the float32 HIP path on a SHORT fixed run (1 prompt, `--drift-steps` PNDM steps): the parity gate
-    # (latent RMS <= 1e-3 vs the oracle) is met by the float32 path; this is what the benchmarked precision gives up
+    # The float32 pipeline on the matrix cores (every float32 product as three float16 MFMA passes: csrc/gemm_split.hip,
+    # attention_split.hip) is the path INSIDE the north star's 1e-3 latent-RMS gate (tests/test_pipeline_gpu.py: ~1e-5 against
+    # the CPU oracle at full SD-1.5 width).  It is timed here on the full workload beside the headline (`tolerance_path`), and
+    # it is the reference of the drift of the benchmarked 16-bit precision on a SHORT fixed run (1 prompt, `--drift-steps` PNDM
+    # steps), absolute and relative to the latent RMS.  Its own distance from the exact float32 FMA kernels is measured on the
+    # same short run.
     drift = None
-    if rank == 0 and a.dtype in ("bf16", "f16") and not a.no_drift and not tiny:
+    tol_path = None
+    want_tol = not a.no_tolerance_path and not tiny and a.dtype in ("bf16", "f16")
+    want_drift = not a.no_drift and not tiny and a.dtype in ("bf16", "f16")
+    if rank == 0 and (want_tol or want_drift):
+        from gm_diffusion import hip_ops
+
+        rms = lambda x, y: float(((x.double() - y.double()) ** 2).mean().sqrt().item())
         try:
+            prev_mode = hip_ops.set_f32_mode("split")
             f_unet = UNet2DConditionModel(in_channels=4, **ucfg).load_state_dict(unet.state_dict()).to(dev, torch.float32)
             f_gm = UNet2DConditionModel(in_channels=8, **ucfg).load_state_dict(gm_unet.state_dict()).to(dev, torch.float32)
-            f_pipe = make_pipe(f_unet, f_gm, vae)
+            f_vae = AutoencoderKL(**vcfg).load_state_dict(vae.state_dict()).to(dev, torch.float32)
+            f_pipe = make_pipe(f_unet, f_gm, f_vae)
             pe1, ne1, la1 = pos[:1].contiguous(), neg[:1].contiguous(), lat[:1].contiguous()
-            _, s_b, g_b = step(pipe, vae, pe1, ne1, la1, a.drift_steps)
-            _, s_f, g_f = step(f_pipe, vae, pe1, ne1, la1, a.drift_steps)
-            rms = lambda x, y: float(((x.double() - y.double()) ** 2).mean().sqrt().item())
-            drift = {"sdr": round(rms(s_b, s_f), 6), "gm": round(rms(g_b, g_f), 6), "latent_rms": round(float(s_f.double().pow(2).mean().sqrt().item()), 4),
-                     "pndm_steps": a.drift_steps, "prompts": 1, "resolution": a.res,
-                     "note": f"RMS difference of the final latents, {a.dtype} path vs the float32 HIP path (same weights, seed, embeddings); "
-                             "north-star gate 1e-3 is met by the float32 path against the oracle (tests/test_pipeline_gpu.py)"}
-            del f_pipe, f_unet, f_gm
+            _, s_f, g_f = step(f_pipe, f_vae, pe1, ne1, la1, a.drift_steps)
+            lat_rms = float(s_f.double().pow(2).mean().sqrt().item())
+            if want_drift:
+                _, s_b, g_b = step(pipe, vae, pe1, ne1, la1, a.drift_steps)
+                d_s, d_g = rms(s_b, s_f), rms(g_b, g_f)
+                drift = {"sdr": round(d_s, 6), "gm": round(d_g, 6), "latent_rms": round(lat_rms, 4),
+                         "sdr_rel": float("%.3g" % (d_s / lat_rms)), "gm_rel": float("%.3g" % (d_g / float(g_f.double().pow(2).mean().sqrt().item()))),
+                         "pndm_steps": a.drift_steps, "prompts": 1, "resolution": a.res,
+                         "note": f"RMS difference of the final latents, {a.dtype} path vs the float32 HIP path on the matrix cores (same weights, "
+                                 "seed, embeddings); *_rel = divided by the RMS of the reference latents (the synthetic weights blow the latents "
+                                 "up); the north-star gate 1e-3 is absolute and is met by the float32 path: see tolerance_path"}
+            if want_tol:
+                step(f_pipe, f_vae)  # warm-up: graph capture of the float32 forwards at the full batch
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(a.tolerance_steps):
+                    step(f_pipe, f_vae)
+                torch.cuda.synchronize()
+                t_tol = time.perf_counter() - t1
+                # the split path against the exact float32 FMA kernels, same short run
+                hip_ops.set_f32_mode("exact")
+                e_unet = UNet2DConditionModel(in_channels=4, **ucfg).load_state_dict(unet.state_dict()).to(dev, torch.float32)
+                e_gm = UNet2DConditionModel(in_channels=8, **ucfg).load_state_dict(gm_unet.state_dict()).to(dev, torch.float32)
+                e_pipe = make_pipe(e_unet, e_gm, f_vae)
+                e_pipe.use_hip_graphs = False
+                sdr_e, gm_e = e_pipe(prompt_embeds=pe1, negative_prompt_embeds=ne1, latents=la1, height=a.res, width=a.res,
+                                     num_inference_steps=a.drift_steps, guidance_scale=7.5, output_type="latent")
+                torch.cuda.synchronize()
+                hip_ops.set_f32_mode("split")
+                tol_path = {
+                    "dtype": "f32 (float32 tensors; every contraction as three float16 MFMA passes, f16 hi + f16 lo operands, fp32 accumulate)",
+                    "images_per_s": round(B * a.tolerance_steps / t_tol, 4), "ms_per_step": round(t_tol / a.tolerance_steps * 1e3, 1),
+                    "steps": a.tolerance_steps, "workload": "same as config.workload (full batch, all inference steps, 2 float32 VAE decodes + tail)",
+                    "latent_rms_vs_f32": {"sdr": float("%.3g" % rms(s_f, sdr_e)), "gm": float("%.3g" % rms(g_f, gm_e)),
+                                          "sdr_rel": float("%.3g" % (rms(s_f, sdr_e) / lat_rms)), "reference": "exact float32 FMA kernels (GMD_F32_MODE=exact)",
+                                          "pndm_steps": a.drift_steps, "prompts": 1},
+                    "gate": "north star: latent RMS <= 1e-3 vs the float32 reference; tests/test_pipeline_gpu.py holds this path to it against "
+                            "the CPU oracle (BASELINE config 1 at full SD-1.5 width: 1e-5)",
+                }
+                del e_pipe, e_unet, e_gm
+            del f_pipe, f_unet, f_gm, f_vae
+            hip_ops.set_f32_mode(prev_mode)
             torch.cuda.empty_cache()
         except Exception as e:  # pragma: no cover
-            drift = {"error": repr(e)}
+            drift = drift or {"error": repr(e)}
+            tol_path = tol_path or {"error": repr(e)}
 
     if rank == 0:
         roof = None
         kernels = {}
         if timer is not None:
             full = timer.summary()
-            mfma_peak = BF16_DENSE_PEAK_TFLOPS if a.dtype in ("bf16", "f16") else F32_VECTOR_PEAK_TFLOPS  # f16 MFMA = bf16 rate
+            # f16 MFMA = bf16 rate; float32 runs on the same matrix cores in three float16 passes (algorithmic FLOPs are counted
+            # once, so a perfect three-pass kernel would read 1/3) unless GMD_F32_MODE=exact selects the vector FMA kernels
+            from gm_diffusion import hip_ops as _ops
+            mfma_peak = BF16_DENSE_PEAK_TFLOPS if (a.dtype in ("bf16", "f16") or _ops.f32_split()) else F32_VECTOR_PEAK_TFLOPS
             all_ms = sum(v["ms"] for v in full.values())
             for k, v in full.items():
                 e = {"launches": v["launches"], "ms": round(v["ms"], 3), "avg_us": round(v["avg_us"], 2), "share": round(v["ms"] / all_ms, 3)}
@@ -341,7 +394,7 @@ def main():
                        "parallelism": f"prompt-batch sharding x{world}, RCCL broadcast of text hidden states + latents",
                        "rccl_world_size": dist.get_world_size() if use_dist else None},
             "outputs_finite": finite, "graph_vs_eager_max_abs_diff": path_diff, "setup_s": round(t_build, 1),
-            "latent_rms_vs_f32": drift, "kernels": kernels, "roofline": roof,
+            "latent_rms_vs_f32": drift, "tolerance_path": tol_path, "kernels": kernels, "roofline": roof,
         }
         if a.checksum:
             res["output_sha256"] = hashlib.sha256(out["hdr_u16"].cpu().numpy().tobytes()).hexdigest()
