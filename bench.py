@@ -197,9 +197,11 @@ def main():
         return p
 
     t_build = time.perf_counter()
-    unet = UNet2DConditionModel(in_channels=4, **ucfg).init_random(1234).to(dev, dtype)
-    gm_unet = UNet2DConditionModel(in_channels=8, **ucfg).init_random(1238).to(dev, dtype)
-    vae = AutoencoderKL(**vcfg).init_random(1334).to(dev, dtype)
+    # synthetic weights are drawn by the DEVICE generator (same seed -> the same weights on every rank): N ranks each drawing
+    # 1.8 G host randoms on cpu_count/N threads would be the longest phase of a multi-GPU run, in front of the first collective
+    unet = UNet2DConditionModel(in_channels=4, **ucfg).init_random(1234, device=dev).to(dev, dtype)
+    gm_unet = UNet2DConditionModel(in_channels=8, **ucfg).init_random(1238, device=dev).to(dev, dtype)
+    vae = AutoencoderKL(**vcfg).init_random(1334, device=dev).to(dev, dtype)
     pipe = make_pipe(unet, gm_unet, vae)
 
     if a.global_batch:
@@ -217,8 +219,9 @@ def main():
         pos = torch.randn(total, 77, cross, generator=ge)
         neg = torch.randn(total, 77, cross, generator=ge)
         lat = torch.randn(total, 4, h, h, generator=torch.Generator("cpu").manual_seed(42))
-    pos, neg, lat, _ = gdist.shard_prompt_batch(pos, neg, lat, total, (77, cross), (4, h, h), torch.float32, dev,
-                                                force=use_dist)
+    # the text hidden states travel in the model dtype (north star: "RCCL broadcast of text-encoder hidden states"; 15 MB at
+    # batch 64 in bf16), rounded on rank 0 exactly as the UNet's prepare_context would round them; the latents stay float32
+    pos, neg, lat, _ = gdist.shard_prompt_batch(pos, neg, lat, total, (77, cross), (4, h, h), dtype, dev, force=use_dist)
     pos, neg, lat = pos.to(dev), neg.to(dev), lat.to(dev)
     unet._ensure(); gm_unet._ensure(); vae._ensure()
     torch.cuda.synchronize()

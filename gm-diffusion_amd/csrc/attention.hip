@@ -541,6 +541,10 @@ __global__ __launch_bounds__(256, 4) void attn40_kernel(const AttnParams p) {
     }
 
     // ---- DMA plan: 640 16-byte chunks per tile (K 320 + V^T 320) = three pieces per thread, the third for waves 0, 1 ----
+    // issue() and wait_tile() below are tied through these two counts: a wave's counted vmcnt leaves exactly ONE younger
+    // tile's pieces in flight, so wait_tile must name the number of pieces issue() gives THAT wave per tile.
+    constexpr int kPiecesW01 = 3, kPiecesW23 = 2;
+    static_assert((2 * kPiecesW01 + 2 * kPiecesW23) * 64 == KV * (D / 8) + D * (KV / 8), "every 16-byte chunk of a K / V^T tile is one lane of one piece");
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
     u32x4 dK, dV;
     {
@@ -581,16 +585,16 @@ __global__ __launch_bounds__(256, 4) void attn40_kernel(const AttnParams p) {
             ks_off = vs_off = 0;
         }
         const unsigned sb = lds_base + (unsigned)stage * kStage;
-        dma16(dK, sb + dst0, a0, ks_off);
-        if (wuni == 0) dma16(dK, sb + dst1, a1, ks_off);
+        dma16(dK, sb + dst0, a0, ks_off);                    // piece 1: every wave
+        if (wuni == 0) dma16(dK, sb + dst1, a1, ks_off);     // piece 2: every wave
         else dma16(dV, sb + dst1, a1, vs_off);
-        if (wuni < 2) dma16(dV, sb + dst2, a2, vs_off);
+        if (wuni < 2) dma16(dV, sb + dst2, a2, vs_off);      // piece 3: waves 0, 1 only (kPiecesW01 = 3, kPiecesW23 = 2)
     };
     // wait until this wave's pieces of the oldest tile in flight have landed (`more`: a younger tile stays in flight)
     auto wait_tile = [&](bool more) {
         if (!more) attn_wait_vmcnt<0>();
-        else if (wuni < 2) attn_wait_vmcnt<3>();
-        else attn_wait_vmcnt<2>();
+        else if (wuni < 2) attn_wait_vmcnt<kPiecesW01>();
+        else attn_wait_vmcnt<kPiecesW23>();
     };
     auto first_product = [&](const unsigned char* Sb, int t) {
         f32x16 acc;

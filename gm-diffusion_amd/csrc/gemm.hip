@@ -977,9 +977,19 @@ int conv_channel_block(int B, int Hin, int Win, int Cin, int Cout, int dtype) {
     return best;
 }
 
+// Kernel-tuning override (debug only: tools/, never the product path).  It takes effect only in a process that has
+// GMD_TUNING=1 in its environment -- both the GMD_GEMM_FORCE seed read when the library is loaded and the in-process
+// gmd_gemm_plan_override() -- and every forced plan still passes plan_unsupported() below, the ONE place that refuses a
+// kernel lacking the epilogue a launch asks for (round 2: five memory-access faults of tools/bench_graph_ops.py under forced
+// odd-TN ring tiles, whose plain epilogue stored [M, N] into the [M, N/2] output of the fused-GEGLU projection).
+bool tuning_enabled() {
+    const char* t = getenv("GMD_TUNING");
+    return t && t[0] == '1';
+}
 struct Force {
     int bm = 0, bn = 0, pf = 0, ks = 0;
     Force() {
+        if (!tuning_enabled()) return;
         if (const char* f = getenv("GMD_GEMM_FORCE")) sscanf(f, "%d,%d,%d,%d", &bm, &bn, &pf, &ks);
     }
 };
@@ -1064,34 +1074,38 @@ bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
            M % 128 == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0;
 }
 
+// The one place that refuses a plan (heuristic or forced) whose kernel lacks an epilogue the launch asks for; nullptr = fine.
+//   * GEGLU pairs value / gate tiles of 16 columns inside a wave: only kernels with an EVEN number of column tiles per wave
+//     implement it (128x128 and 64x64 register / DMA kernels, ring tiles with TN = 2 or 4) and never with split-K -- any
+//     other kernel's plain epilogue would store [M, N] into the [M, N/2] output;
+//   * column statistics come out of the full-tile row epilogue of the two default 128-row ring kernels only.
+const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch) {
+    if (p.act == GMD_ACT_GEGLU) {
+        const bool odd_tn = pl.bn == 160 || (pl.pf >= 100 && pl.bm == 64 && pl.bn == 64);  // TN = 5 / ring<1,4,1,.>: TN = 1
+        if (odd_tn || pl.ksplit > 1 || p.out_f32) return "has no GEGLU epilogue";
+    }
+    if (p.colstats) {
+        const bool rows_ok = !p.out_f32 && p.act != GMD_ACT_GEGLU && (p.ldc & 7) == 0 && (p.residual == nullptr || (p.ldr & 7) == 0) &&
+                             (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0));
+        if (!rows_ok || !colstats_plan_ok(pl, p.M, p.N, batch, p.cs_bucket))
+            return "cannot emit column statistics (they need the full-tile row epilogue of an unsplit 128-row ring launch: ask "
+                   "gmd_gemm_colstats_plan first)";
+    }
+    return nullptr;
+}
+
 template <typename HT, bool CONV>
 int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     constexpr bool kTune = std::is_same<HT, bf16_t>::value;
     hipError_t e = hipSuccess;
     const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
-    if (p.colstats) {
-        const bool rows_ok = !p.out_f32 && p.act != GMD_ACT_GEGLU && (p.ldc & 7) == 0 && (p.residual == nullptr || (p.ldr & 7) == 0) &&
-                             (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0));
-        if (!rows_ok || !colstats_plan_ok(pl, p.M, p.N, batch, p.cs_bucket)) {
-            gmd_set_error("%s: column statistics need the full-tile row epilogue of an unsplit 128-row ring launch "
-                          "(plan %dx%d pf=%d ksplit=%d, M=%d N=%d bucket=%d): ask gmd_gemm_colstats_plan first",
-                          name, pl.bm, pl.bn, pl.pf, pl.ksplit, p.M, p.N, p.cs_bucket);
-            return GMD_ERR_UNSUPPORTED;
-        }
+    if (const char* why = plan_unsupported(pl, p, batch)) {
+        gmd_set_error("%s: plan %dx%d pf=%d ksplit=%d (M=%d N=%d bucket=%d) %s", name, pl.bm, pl.bn, pl.pf, pl.ksplit, p.M, p.N, p.cs_bucket, why);
+        return GMD_ERR_UNSUPPORTED;
     }
     p.ksplit = pl.ksplit;
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
-    // the fused GEGLU epilogue pairs value / gate tiles of 16 columns inside a wave: only kernels with an even number of
-    // column tiles per wave implement it (the heuristic picks one; a plan override must not bypass that -- the plain
-    // epilogue would write [M, N] into the [M, N/2] output)
-    if (p.act == GMD_ACT_GEGLU) {
-        const bool ring_odd = pl.pf >= 100 ? (pl.bn == 160 || (pl.bm == 64 && pl.bn == 64)) : (pl.pf == 0 && pl.bm == 128 && pl.bn == 160);
-        if (ring_odd || pl.bn == 160 || pl.ksplit > 1) {
-            gmd_set_error("%s: plan %dx%d pf=%d ksplit=%d has no GEGLU epilogue", name, pl.bm, pl.bn, pl.pf, pl.ksplit);
-            return GMD_ERR_UNSUPPORTED;
-        }
-    }
     bool done = false;
     if constexpr (kTune) {
         done = true;
@@ -1168,6 +1182,10 @@ extern "C" {
 
 int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit) {
     GMD_REQUIRE(bm >= 0 && bn >= 0 && pf >= 0 && ksplit >= 0, "gmd_gemm_plan_override: negative value");
+    if (!tuning_enabled() && (bm | bn | pf | ksplit) != 0) {
+        gmd_set_error("gmd_gemm_plan_override: kernel-tuning overrides are a debug facility; set GMD_TUNING=1 in the environment to use them");
+        return GMD_ERR_UNSUPPORTED;
+    }
     g_force.bm = bm; g_force.bn = bn; g_force.pf = pf; g_force.ks = ksplit;
     return GMD_OK;
 }

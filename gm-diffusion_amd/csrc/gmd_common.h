@@ -85,6 +85,9 @@ template <> struct Half<bf16_t> {
 };
 template <> struct Half<f16_t> {
     static constexpr unsigned kOne = 0x3C00u;
+    // Not saturating: a value beyond 65504 becomes infinite.  The callers stay inside the range by construction: attention
+    // stores O, a convex combination of V's (finite float16) values, and carries P <= 2^14 (the lagged-stabiliser window of
+    // the float16 kernels); GEMM / conv outputs beyond the range are the documented limit of the float16 path.
     __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
         const f16x2 v = {(_Float16)lo, (_Float16)hi};  // round-to-nearest-even conversions
         return __builtin_bit_cast(unsigned, v);

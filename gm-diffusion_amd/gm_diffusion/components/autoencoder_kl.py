@@ -126,9 +126,9 @@ class AutoencoderKL(_HipModule):
             m.to(torch_dtype)
         return m
 
-    def init_random(self, seed=1334, with_encoder=False):
+    def init_random(self, seed=1334, with_encoder=False, device=None):
         self.with_encoder = with_encoder
-        g = torch.Generator("cpu").manual_seed(seed)
+        g = torch.Generator(device or "cpu").manual_seed(seed)
         keys = self.expected_keys()
         sd = {}
         for k, shp in keys.items():
@@ -139,7 +139,7 @@ class AutoencoderKL(_HipModule):
             fan_in = 1
             for s_ in wshape[1:]:
                 fan_in *= s_
-            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * fan_in ** -0.5
+            sd[k] = (torch.rand(shp, generator=g, device=g.device) * 2 - 1) * fan_in ** -0.5
         return self.load_state_dict(sd)
 
     # ---- weights -----------------------------------------------------------------------------

@@ -346,21 +346,24 @@ class UNet2DConditionModel(_HipModule):
         self._internal_dict = type(self._internal_dict)(cfg)
         return self.load_state_dict(sd)
 
-    def init_random(self, seed=1234):
+    def init_random(self, seed=1234, device=None):
         """Deterministic synthetic weights (uniform +-1/sqrt(fan_in), unit norms) for benchmarks; no checkpoint
-        exists offline."""
-        g = torch.Generator("cpu").manual_seed(seed)
+        exists offline.  ``device``: draw them with that device's generator instead of the host's (the
+        multi-GPU bench: 8 ranks each drawing 1.8 G host randoms would be the longest phase of the run); the values then
+        differ from the host draw but are the same on every rank."""
+        g = torch.Generator(device or "cpu").manual_seed(seed)
+        keys = self.expected_keys()
         sd = {}
-        for k, shp in self.expected_keys().items():
+        for k, shp in keys.items():
             if ".norm" in k or k.startswith("conv_norm_out") or k.endswith("norm.weight") or k.endswith("norm.bias"):
                 sd[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
                 continue
-            wshape = self.expected_keys()[k.rsplit(".", 1)[0] + ".weight"]
+            wshape = keys[k.rsplit(".", 1)[0] + ".weight"]
             fan_in = 1
             for s_ in wshape[1:]:
                 fan_in *= s_
             bound = fan_in ** -0.5
-            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+            sd[k] = (torch.rand(shp, generator=g, device=g.device) * 2 - 1) * bound
         return self.load_state_dict(sd)
 
     # ------------------------------------------------------------------------------------------

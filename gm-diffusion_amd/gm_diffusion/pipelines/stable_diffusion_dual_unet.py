@@ -1,3 +1,23 @@
+# Portions of this file keep API-surface text (the ``__call__`` / constructor signatures, ``encode_prompt``, ``check_inputs``
+# error messages, the property block and the output tail) of diffusers' ``StableDiffusionPipeline``, which the reference's
+# pipeline files are copies of with ~40 changed lines each (their header, reproduced as the Apache License 2.0 requires):
+#
+#     Copyright 2024 The HuggingFace Team. All rights reserved.
+#
+#     Licensed under the Apache License, Version 2.0 (the "License");
+#     you may not use this file except in compliance with the License.
+#     You may obtain a copy of the License at
+#
+#         http://www.apache.org/licenses/LICENSE-2.0
+#
+#     Unless required by applicable law or agreed to in writing, software
+#     distributed under the License is distributed on an "AS IS" BASIS,
+#     WITHOUT WARRANTIES OR CONDITIONS OF ANY KIND, either express or implied.
+#     See the License for the specific language governing permissions and
+#     limitations under the License.
+#
+# Changes from that text: the LoRA / textual-inversion / IP-adapter branches are removed, the denoising loop, latent step,
+# UNet / VAE calls and the decode tail are new (hand-written HIP kernels behind gm_diffusion.hip_ops).
 """
 ``StableDiffusionDualUNetPipeline`` -- the Stage-3 text->HDR path: an SDR UNet (with
 classifier-free guidance) and a GM UNet (conditional only, fed the SDR x0-prediction) are stepped

@@ -1,3 +1,23 @@
+# Portions of this file keep API-surface text (the ``__call__`` / constructor signatures, ``encode_prompt``, ``check_inputs``
+# error messages, the property block and the output tail) of diffusers' ``StableDiffusionPipeline``, which the reference's
+# pipeline files are copies of with ~40 changed lines each (their header, reproduced as the Apache License 2.0 requires):
+#
+#     Copyright 2024 The HuggingFace Team. All rights reserved.
+#
+#     Licensed under the Apache License, Version 2.0 (the "License");
+#     you may not use this file except in compliance with the License.
+#     You may obtain a copy of the License at
+#
+#         http://www.apache.org/licenses/LICENSE-2.0
+#
+#     Unless required by applicable law or agreed to in writing, software
+#     distributed under the License is distributed on an "AS IS" BASIS,
+#     WITHOUT WARRANTIES OR CONDITIONS OF ANY KIND, either express or implied.
+#     See the License for the specific language governing permissions and
+#     limitations under the License.
+#
+# Changes from that text: the LoRA / textual-inversion / IP-adapter branches are removed, the denoising loop, latent step,
+# UNet / VAE calls and the decode tail are new (hand-written HIP kernels behind gm_diffusion.hip_ops).
 """
 ``StableDiffusionGMPipeline`` -- single 8-channel UNet that denoises the gain-map (GM) latent
 conditioned on a given SDR latent.  Drop-in mirror of the reference class at
@@ -319,6 +339,8 @@ class _GMPipelineBase(DiffusionPipeline):
         return (latents.is_cuda and isinstance(scheduler, (PNDMScheduler, DPMSolverMultistepScheduler, DDPMScheduler))
                 and isinstance(unet, UNet2DConditionModel))
 
+    PREDRAW_NOISE_BYTES = 512 << 20  # ceiling of the pre-drawn scheduler noise (host pinned copy + device copy)
+
     @staticmethod
     def _predraw_step_noise(schedulers, ts_host, shape, generator, device):
         """Stochastic schedulers on the fused path with a CPU generator: draw the variance noise of EVERY step now, in exactly
@@ -326,7 +348,11 @@ class _GMPipelineBase(DiffusionPipeline):
         stable_diffusion_dual_unet.py:1077, 1093), and move it to the device in one asynchronous copy.  A draw inside the
         loop is a host-side randn + synchronous copy per step, which stops the host from running ahead of the GPU
         (bench.py --scheduler ddpm: 3.67 -> 4.59 images/s).  Returns one list of per-step tensors (or None) per scheduler,
-        or None when there is nothing to pre-draw (deterministic scheduler, device generator, global RNG)."""
+        or None when there is nothing to pre-draw (deterministic scheduler, device generator, global RNG) or when the noise
+        of all steps would exceed PREDRAW_NOISE_BYTES (DDPM's default 1000 steps at 1024x1024, batch 8, two schedulers is
+        ~4 GB on the host AND on the device): the loop then draws per step, as the reference does.
+        Difference from the reference under ``interrupt``: the pre-draw has already advanced the caller's generator for the
+        steps an interrupt later skips; the reference would not have consumed those draws."""
         from ..components.schedulers import DDPMScheduler
 
         if generator is None or not all(isinstance(s_, DDPMScheduler) for s_ in schedulers):
@@ -337,8 +363,14 @@ class _GMPipelineBase(DiffusionPipeline):
         slots = [(i, k) for i, t in enumerate(ts_host) for k, s_ in enumerate(schedulers) if s_.draws_noise(t)]
         if not slots:
             return None
+        nbytes = 4 * len(slots)
+        for d in shape:
+            nbytes *= int(d)
+        if nbytes > StableDiffusionGMPipeline.PREDRAW_NOISE_BYTES:
+            return None
         host = torch.stack([randn_tensor(shape, generator=generator, device="cpu", dtype=torch.float32) for _ in slots])
-        dev = host.pin_memory().to(device, non_blocking=True) if host.numel() else host.to(device)
+        on_gpu = torch.device(device).type == "cuda"
+        dev = host.pin_memory().to(device, non_blocking=True) if (host.numel() and on_gpu) else host.to(device)
         out = [[None] * len(ts_host) for _ in schedulers]
         for n, (i, k) in enumerate(slots):
             out[k][i] = dev[n]

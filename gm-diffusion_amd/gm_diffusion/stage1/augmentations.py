@@ -16,8 +16,9 @@ import torch
 from .. import hip_ops as ops
 
 
-class OutOfScopeError(NotImplementedError):
-    """A reference entry point outside the Stage-3 hot path was called."""
+class OutOfScopeError(NotImplementedError, AttributeError):
+    """A reference entry point outside the Stage-3 hot path was called.  Also an ``AttributeError``, so
+    ``hasattr(obj, "gamma")`` answers False instead of raising."""
 
 
 def _as_f32(img: torch.Tensor) -> torch.Tensor:
@@ -44,13 +45,29 @@ class RandomExposureAdjust:
         """The integer codes behind :meth:`discretize_to_uint16` (uint16 tensor, same shape)."""
         return ops.discretize_u16(_as_f32(img), codes=True)[1]
 
+    # -- the reference's Stage-1 members (augmentations.py:10-80): named explicitly so that class-level access
+    # (``RandomExposureAdjust.sample_camera_curve()``) and instance access fail the same, loud way ------------------------
     def __call__(self, *args, **kwargs):
         raise OutOfScopeError(self._OUT_OF_SCOPE)
 
-    def __getattr__(self, name):
-        if name in ("hdr_to_ldr", "sample_camera_curve", "apply_inv_sigmoid_curve", "exposure_levels", "gamma", "prob"):
-            raise OutOfScopeError(self._OUT_OF_SCOPE)
-        raise AttributeError(name)
+    @staticmethod
+    def hdr_to_ldr(*args, **kwargs):
+        raise OutOfScopeError(RandomExposureAdjust._OUT_OF_SCOPE)
+
+    @staticmethod
+    def sample_camera_curve(*args, **kwargs):
+        raise OutOfScopeError(RandomExposureAdjust._OUT_OF_SCOPE)
+
+    @staticmethod
+    def apply_inv_sigmoid_curve(*args, **kwargs):
+        raise OutOfScopeError(RandomExposureAdjust._OUT_OF_SCOPE)
+
+    def _out_of_scope_attr(self):
+        raise OutOfScopeError(self._OUT_OF_SCOPE)
+
+    exposure_levels = property(_out_of_scope_attr)
+    gamma = property(_out_of_scope_attr)
+    prob = property(_out_of_scope_attr)
 
     def __repr__(self) -> str:  # pragma: no cover
         return "RandomExposureAdjust(<hot-path subset: discretize_to_uint16, uint16_codes>)"

@@ -172,10 +172,13 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
  * stable_diffusion_gm.py:1051,1094 and stable_diffusion_dual_unet.py:1052,1083)
  * ---------------------------------------------------------------------------------- */
 
-/* Tuning hook (tools/bench_gemm.py, tools/check_ring.py; never called by the product path): pin the tile (bm x bn), the
- * operand pipeline (pf: 9 = LDS-DMA, 1/2 = register staged, 1xx = ring variants) and the split-K factor of every later
- * gmd_gemm_nt / gmd_conv3x3 launch of this process; 0 keeps the heuristic for that field, (0,0,0,0) restores it.  The
- * environment variable GMD_GEMM_FORCE="bm,bn,pf,ksplit" seeds the same override once, when the library is loaded. */
+/* DEBUG ONLY -- kernel-tuning hook of tools/ (bench_gemm.py, check_ring.py, bench_graph_ops.py); never called by the product
+ * path and refused (GMD_ERR_UNSUPPORTED) unless the process has GMD_TUNING=1 in its environment.  Pins the tile (bm x bn), the
+ * operand pipeline (pf: 9 = LDS-DMA, 1/2 = register staged, 1xx = ring variants) and the split-K factor of every later 16-bit
+ * gmd_gemm_nt / gmd_conv3x3 launch of this process; 0 keeps the heuristic for that field, (0,0,0,0) restores it (always
+ * allowed).  GMD_GEMM_FORCE="bm,bn,pf,ksplit" seeds the same override when the library is loaded, under the same GMD_TUNING
+ * gate.  A forced plan whose kernel lacks the epilogue a launch asks for (fused GEGLU, column statistics) is refused at the
+ * launch, never run. */
 int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit);
 
 /* C[b] = act(alpha * A[b] @ W[b]^T + bias + rowbias + residual).

@@ -449,7 +449,42 @@ def test_random_exposure_adjust_is_hot_path_subset_only():
     aug = RandomExposureAdjust(gamma=2.2, prob=1.0)
     with pytest.raises(OutOfScopeError):
         aug(torch.zeros(3, 8, 8))
+    for call in (aug.hdr_to_ldr, RandomExposureAdjust.sample_camera_curve, RandomExposureAdjust.apply_inv_sigmoid_curve):
+        with pytest.raises(OutOfScopeError):  # instance and class access behave the same
+            call()
     with pytest.raises(OutOfScopeError):
-        aug.hdr_to_ldr
+        aug.gamma
+    assert not hasattr(aug, "gamma") and not hasattr(aug, "exposure_levels")  # OutOfScopeError is an AttributeError too
+    with pytest.raises(NotImplementedError):
+        aug.prob
     with pytest.raises(HipExtensionError):  # the in-scope member is a HIP kernel: host tensors are refused
         RandomExposureAdjust.discretize_to_uint16(torch.zeros(4))
+
+
+def test_predrawn_scheduler_noise_is_capped_and_ordered():
+    """DDPM on the fused path pre-draws the variance noise of every step from a CPU generator, SDR before GM in each
+    iteration (stable_diffusion_dual_unet.py:1077, 1093); above PREDRAW_NOISE_BYTES it declines and the loop draws per step."""
+    from gm_diffusion.components import DDPMScheduler
+    from gm_diffusion.components.image_processor import randn_tensor
+    from gm_diffusion.pipelines import StableDiffusionGMPipeline as P
+
+    s1 = DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    s1.set_timesteps(4)
+    s2 = DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    s2.set_timesteps(4)
+    ts = [int(t) for t in s1.timesteps]
+    shape = (2, 4, 8, 8)
+    pre = P._predraw_step_noise([s1, s2], ts, shape, torch.Generator().manual_seed(5), "cpu")
+    g = torch.Generator().manual_seed(5)
+    for i, t in enumerate(ts):
+        for k, s_ in enumerate((s1, s2)):
+            if s_.draws_noise(t):
+                assert torch.equal(pre[k][i], randn_tensor(shape, generator=g, device="cpu", dtype=torch.float32)), (i, k)
+            else:
+                assert pre[k][i] is None
+    old = P.PREDRAW_NOISE_BYTES
+    try:
+        P.PREDRAW_NOISE_BYTES = 4 * 2 * 4 * 8 * 8 * 3  # room for three draws only
+        assert P._predraw_step_noise([s1, s2], ts, shape, torch.Generator().manual_seed(5), "cpu") is None
+    finally:
+        P.PREDRAW_NOISE_BYTES = old

@@ -739,14 +739,25 @@ def test_plan_override_cannot_bypass_geglu_tile_rule():
     w = (torch.randn(640, 320, generator=g) * 0.05).bfloat16().to(DEV)
     b = torch.randn(640, generator=g).to(DEV)
     want = o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU)
+    had = os.environ.pop("GMD_TUNING", None)
+    assert lib().gmd_gemm_plan_override(128, 160, 9, 1) != 0, "overrides are refused outside a GMD_TUNING=1 process"
+    assert torch.equal(o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU), want)  # ... and the refused override left the heuristic in place
+    os.environ["GMD_TUNING"] = "1"
     try:
-        lib().gmd_gemm_plan_override(128, 160, 9, 1)
-        with pytest.raises(HipExtensionError):
-            o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU)
+        # the plans of the round-2 fault record (tools/bench_graph_ops.py under 64,64,103 / 64,64,104 / 128,160,123 / 128,160,124:
+        # odd number of 16-column tiles per wave, no GEGLU epilogue) and the default-pipeline 128x160 tile
+        for plan in ((128, 160, 9, 1), (64, 64, 103, 0), (64, 64, 104, 0), (128, 160, 123, 0), (128, 160, 124, 0), (128, 128, 9, 2)):
+            assert lib().gmd_gemm_plan_override(*plan) == 0
+            with pytest.raises(HipExtensionError):
+                o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU)
         lib().gmd_gemm_plan_override(128, 128, 9, 1)  # an even-tile kernel: allowed, same result as the heuristic's choice
         got = o.gemm_nt(a, w, bias=b, act=o.ACT_GEGLU)
     finally:
         lib().gmd_gemm_plan_override(0, 0, 0, 0)
+        if had is None:
+            os.environ.pop("GMD_TUNING", None)
+        else:
+            os.environ["GMD_TUNING"] = had
     assert rel_err(got.float(), want.float()) < 1e-2
 
 
@@ -890,3 +901,27 @@ def test_attention_d40_dma_ring_is_repeatable_beside_another_stream(dtype, B, Nq
         differ += int(not torch.equal(o.attention(q, k, vt, H, Nk, 40 ** -0.5), first))
     torch.cuda.synchronize()
     assert differ == 0
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("D,Nk", [(40, 77), (40, 203), (80, 77), (40, 130)])
+def test_attention_partial_last_tile_never_reads_poisoned_memory(dtype, D, Nk):
+    """Partial last key tile (Nk % 64 != 0, Nk % 8 != 0): K rows at and beyond Nk exist in memory and are NaN, the V^T row
+    padding beyond Nk is NaN -- the kernels' range-checked loads / masking / LDS zeroing must keep every NaN out (the d = 40
+    kernel stages tiles by LDS-DMA with hand-counted waits: csrc/attention.hip, attn40_kernel)."""
+    o = ops()
+    H, B, Nq = 8, 2, 192
+    C = H * D
+    g = torch.Generator().manual_seed(Nk + D)
+    q = torch.randn(B, Nq, C, generator=g).to(dtype)
+    kfull = torch.full((B, Nk + 70, C), float("nan")).to(dtype)  # rows >= Nk: poison
+    k = torch.randn(B, Nk, C, generator=g).to(dtype)
+    kfull[:, :Nk] = k
+    v = torch.randn(B, Nk, C, generator=g).to(dtype)
+    ld = (Nk + 7) // 8 * 8 + 16
+    vt = torch.full((B, C, ld), float("nan")).to(dtype)
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    ref = _attn_ref(q.float(), k.float(), v.float(), H, D ** -0.5)
+    got = o.attention(q.to(DEV), kfull.to(DEV), vt.to(DEV), H, Nk, D ** -0.5)
+    assert torch.isfinite(got.float()).all()
+    assert rel_err(got.float(), ref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)

@@ -251,3 +251,41 @@ def test_sd15_unet_bf16_producer_statistics_path_vs_oracle_and_vs_statistics_lau
     e_ref, e_plain = rel_err(got, ref), rel_err(plain, ref)
     assert e_ref < 3e-2 and e_plain < 3e-2 and e_ref < 1.25 * e_plain + 1e-3, (e_ref, e_plain)
     assert rel_err(got, plain) < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2.5e-2), (torch.float16, 4e-3)])
+def test_cfg_shared_prefix_carries_producer_statistics_through_the_duplication(dtype, tol):
+    """Full-width UNet at 64x64 latents, half precision: the CFG shared prefix duplicates tensors that carry their producer's
+    GroupNorm statistics (``_dup_batch``); the statistics must be duplicated alike.  Shared vs duplicated batch, with the
+    producer statistics on and off, and the statistics path must really be taken."""
+    from gm_diffusion import hip_ops as ops
+    from oracle import fixtures
+
+    hu = _hip_unet(fixtures.build_unet("sd15", 4), dtype)
+    g = torch.Generator().manual_seed(41)
+    lat = torch.randn(4, 4, 64, 64, generator=g)  # 4 unique samples: the prefix launches (M = 16384) still fill the chip with 128-row tiles
+    ctx = torch.randn(8, 77, 768, generator=g)  # [uncond x4, cond x4]
+    hu._ensure()
+    c = hu.prepare_context(ctx.to(DEV))
+    hu.set_timestep(333)
+    out = {}
+    for use in (True, False):
+        ops.USE_COLSTATS = use
+        try:
+            before = ops.colstats_uses
+            full = hu.forward_packed(hu.pack_input(lat.to(DEV), dup=2), 8, 64, 64, c)
+            used_full = ops.colstats_uses - before
+            shared = hu.forward_packed(hu.pack_input(lat.to(DEV), dup=1), 8, 64, 64, c, cfg_shared=True)
+            used_shared = ops.colstats_uses - before - used_full
+        finally:
+            ops.USE_COLSTATS = True
+        if use:
+            # the same GroupNorms are served from producer statistics in both forms: the prefix tensors' statistics survive
+            # the duplication (skip connections and the residual stream included)
+            assert used_full >= 16 and used_shared == used_full, (used_full, used_shared)
+        else:
+            assert used_full == 0 and used_shared == 0
+        assert rel_err(shared, full) < tol, (use, rel_err(shared, full))
+        assert not torch.equal(shared[:4], shared[4:])
+        out[use] = shared
+    assert rel_err(out[True], out[False]) < tol

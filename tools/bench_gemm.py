@@ -3,6 +3,7 @@
 Set GMD_GEMM_FORCE="bm,bn,pf,ksplit" to pin a kernel variant (0 = heuristic)."""
 import os
 import sys
+os.environ.setdefault("GMD_TUNING", "1")  # kernel-plan overrides are a debug facility (include/gmd_hip.h)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gm-diffusion_amd")):

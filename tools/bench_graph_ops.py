@@ -4,6 +4,7 @@ overhead between them; the eager Python front end costs ~10-15 us per call and h
 over `sets` buffer sets so consecutive launches do not find their inputs in L2 / Infinity Cache.
 Usage: bench_graph_ops.py [--batch 8] [--only gemm,conv,ln,gn,attn] [--force bm,bn,pf,ks]"""
 import argparse, os, sys
+os.environ.setdefault("GMD_TUNING", "1")  # kernel-plan overrides are a debug facility (include/gmd_hip.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gm-diffusion_amd")):
     sys.path.insert(0, p)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Plan check: time selected GEMM shapes of the UNet under the heuristic and forced variants (diagnostic)."""
 import os, sys, subprocess
+os.environ.setdefault("GMD_TUNING", "1")  # kernel-plan overrides are a debug facility (include/gmd_hip.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(2048, 2560, 1280), (2048, 1280, 5120), (8192, 640, 2560), (8192, 1280, 640), (1024, 1280, 5120), (4096, 640, 2560), (512, 1280, 5120),
           (512, 2560, 1280), (1024, 2560, 1280), (4096, 1280, 640), (16384, 640, 320), (2048, 1280, 2560), (512, 1280, 2560)]

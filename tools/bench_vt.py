@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """V^T projection (operand-swapped, batched) micro-benchmark: V^T[b] = W_v . x_b^T (diagnostic)."""
 import os, sys
+os.environ.setdefault("GMD_TUNING", "1")  # kernel-plan overrides are a debug facility (include/gmd_hip.h)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gm-diffusion_amd"))
 import torch
 from gm_diffusion import hip_ops as ops

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Correctness + speed of GEMM kernel variants (gmd_gemm_plan_override) against the default kernel, in one process."""
 import os, sys
+os.environ.setdefault("GMD_TUNING", "1")  # kernel-plan overrides are a debug facility (include/gmd_hip.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gm-diffusion_amd"))
 import torch

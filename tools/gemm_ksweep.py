@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Fixed vs per-K-step cost of gmd_gemm_nt: device time (HIP-graph replay, rotated buffers) against K at fixed M, N."""
 import os, sys
+os.environ.setdefault("GMD_TUNING", "1")  # kernel-plan overrides are a debug facility (include/gmd_hip.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gm-diffusion_amd")):
     sys.path.insert(0, p)
