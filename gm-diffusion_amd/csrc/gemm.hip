@@ -1217,7 +1217,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     GMD_REQUIRE(residual == nullptr || out_dtype == dtype || !is16, "gmd_gemm_nt: residual needs out_dtype == dtype");
     GMD_REQUIRE(act == GMD_ACT_NONE || act == GMD_ACT_SILU || act == GMD_ACT_GEGLU || act == GMD_ACT_QUICK_GELU, "gmd_gemm_nt: bad act %d", act);
     if (act == GMD_ACT_GEGLU) {
-        GMD_REQUIRE(is16 && out_dtype == dtype, "gmd_gemm_nt: GEGLU epilogue is implemented for the 16-bit types only");
+        GMD_REQUIRE((is16 && out_dtype == dtype) || split, "gmd_gemm_nt: GEGLU epilogue is implemented for the 16-bit types and the float32 split types");
         GMD_REQUIRE(N % 32 == 0 && ldc >= N / 2 && ldc % 4 == 0 && strideC % 4 == 0, "gmd_gemm_nt: GEGLU needs N %% 32 == 0 and ldc >= N/2");
         GMD_REQUIRE(!residual && !rowbias, "gmd_gemm_nt: GEGLU epilogue takes no residual / rowbias");
     }

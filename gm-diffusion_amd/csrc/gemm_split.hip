@@ -78,6 +78,30 @@ __device__ __forceinline__ void epilogue_regs_f32(const GemmParams& p, const f32
     const bool vec_r = p.residual != nullptr && (p.ldr % 4 == 0) && (p.sR % 4 == 0);
     const bool vec_n = (p.N % 4 == 0);
     const bool vec_rb = vec_n && (p.ldrb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0);
+    if constexpr (TN % 2 == 0) {
+        if (p.act == GMD_ACT_GEGLU) {  // ragged tiles of the fused GEGLU projection (full tiles: epilogue_rows_geglu_f32)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mw + i * 16 + frow;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int n = nw + j * 16 + fq * 4;  // interleaved column of the value group (N % 32 == 0: a pair is whole)
+                    if (n >= p.N) continue;
+                    float o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hv = acc[i][j][e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+                        const float g = acc[i][j + 1][e] * p.alpha + (p.bias ? p.bias[n + 16 + e] : 0.f);
+                        o4[e] = hv * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+                    }
+                    float* o = (float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + (nw + j * 16) / 2 + fq * 4;
+                    *reinterpret_cast<float4*>(o) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = mw + i * 16 + frow;
@@ -190,6 +214,51 @@ __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs_f32
             *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// GEGLU (GEGLU.forward of diffusers: value * gelu_erf(gate)): the W rows are interleaved at load time in 16-row [value | gate]
+// groups, so tile j holds 16 value columns and tile j+1 the matching gate columns IN THE SAME LANE; the product is formed in
+// registers and only the [M, N/2] result is written -- the [tokens, 8C] float32 projection (335 MB per level-0 block at batch 8)
+// never reaches HBM.  Full tiles only (checked by the caller); erf by libm's erff: this is the float32 path.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_geglu_f32(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
+                                                        int z) {
+    static_assert(TM % 2 == 0 && TN % 2 == 0, "halves of two 16-row tiles; value/gate tile pairs");
+    constexpr int NCOL = TN * 8, ROWF = NCOL + 4, CH = NCOL / 4;  // output columns of this wave
+    constexpr int ITER = (32 * CH + 63) / 64;
+    const int frow = lane & 15, fq = lane >> 4;
+    float bz[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float4 t = p.bias ? *reinterpret_cast<const float4*>(p.bias + nw + j * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bz[j][0] = t.x; bz[j][1] = t.y; bz[j][2] = t.z; bz[j][3] = t.w;
+    }
+#pragma unroll
+    for (int h = 0; h < TM / 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                float o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hv = acc[2 * h + i2][j][e] * p.alpha + bz[j][e];
+                    const float g = acc[2 * h + i2][j + 1][e] * p.alpha + bz[j + 1][e];
+                    o4[e] = hv * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)));
+                }
+                *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + (j / 2) * 16 + fq * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < ITER; ++t) {
+            const int idx = lane + 64 * t;
+            const int r = idx / CH, c = idx - r * CH;
+            if (32 * CH % 64 != 0 && r >= 32) continue;
+            *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)(mw + h * 32 + r) * p.ldc + nw / 2 + c * 4) =
+                *reinterpret_cast<const float4*>(strip + r * ROWF + c * 4);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -442,6 +511,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
     constexpr bool strips_fit = (TM % 2 == 0) && ((size_t)NWAVES * kStrip * 4 <= (size_t)NST * kStage);
     if constexpr (strips_fit) {
         const bool full = m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0;
+        if constexpr (TN % 2 == 0) {
+            if (p.act == GMD_ACT_GEGLU && full) {
+                __syncthreads();
+                epilogue_rows_geglu_f32<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, mw, nw, lane, z);
+                return;
+            }
+        }
         if (p.ksplit > 1 && full) {
             __syncthreads();
             epilogue_rows_f32<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, mw, nw, lane, z, ks);
@@ -519,7 +595,12 @@ hipError_t launch_split(const GemmParams& p, int gz, hipStream_t s) {
 
 template <bool CONV, bool WSPLIT>
 int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
-    const SplitPlan pl = make_split_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0);
+    SplitPlan pl = make_split_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0);
+    if (p.act == GMD_ACT_GEGLU) {
+        // value / gate tile pairs inside a wave: even TN (128x128 or 64x64 tiles), unsplit K, every tile full, row epilogue
+        if (pl.bn == 160) pl.bn = 128;
+        pl.ksplit = 1;
+    }
     p.ksplit = pl.ksplit;
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;

@@ -402,14 +402,17 @@ class UNet2DConditionModel(_HipModule):
             t["k2"] = self._lin(f"{b}.attn2.to_k", False)[0]
             t["v2"] = self._wa(self._raw[f"{b}.attn2.to_v.weight"])
             t["o2"] = self._lin(f"{b}.attn2.to_out.0")
-            t["ff1"] = self._lin(f"{b}.ff.net.0.proj")
-            if ops.is_half(self._dtype):
+            if ops.is_half(self._dtype) or self._split_mode():
                 # fused GEGLU epilogue: interleave value / gate rows in groups of 16 so both land in the same MFMA lane
                 wf, bf = self._raw[f"{b}.ff.net.0.proj.weight"], self._raw[f"{b}.ff.net.0.proj.bias"]
                 half = wf.shape[0] // 2
                 wi = torch.stack([wf[:half].reshape(half // 16, 16, -1), wf[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1)
                 bi = torch.stack([bf[:half].reshape(half // 16, 16), bf[half:].reshape(half // 16, 16)], 1).reshape(2 * half)
-                t["ff1"] = (self._act(wi), self._f32(bi))
+                t["ff1"] = (self._wt(wi), self._f32(bi))
+                t["ff1_fused"] = True
+            else:
+                t["ff1"] = self._lin(f"{b}.ff.net.0.proj")
+                t["ff1_fused"] = False
             t["ff2"] = self._lin(f"{b}.ff.net.2")
             t["key"] = k
             self._transformers.append(t)
@@ -551,7 +554,7 @@ class UNet2DConditionModel(_HipModule):
         h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h)
         # GEGLU feed-forward
         n3 = ops.layernorm(h, *t["norm3"])
-        if ops.is_half(self._dtype):
+        if t["ff1_fused"]:
             f = ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1], act=ops.ACT_GEGLU)  # h * gelu(g) formed in the GEMM epilogue
         else:
             f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))

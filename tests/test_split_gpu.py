@@ -305,3 +305,23 @@ def test_split_attention_rejects_other_modes():
     q = torch.randn(1, 64, 80, device=DEV)
     with pytest.raises(o.HipExtensionError):
         o.attention(q, q, torch.randn(1, 80, 64, device=DEV), 2, 64, 0.15)
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (4096, 640), (64, 1280), (33, 64), (16384, 320)])
+def test_split_fused_geglu_epilogue(M, C):
+    """ff.net.0.proj with the value / gate rows interleaved in 16-row groups: value * gelu_erf(gate) out of the GEMM epilogue
+    (full tiles through the LDS row epilogue, ragged tiles from registers), against float64."""
+    o = ops()
+    g = torch.Generator().manual_seed(M + C)
+    a = torch.randn(M, C, generator=g)
+    wf = torch.randn(8 * C, C, generator=g) / math.sqrt(C)
+    bf = torch.randn(8 * C, generator=g)
+    half = 4 * C
+    wi = torch.stack([wf[:half].reshape(half // 16, 16, -1), wf[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1)
+    bi = torch.stack([bf[:half].reshape(half // 16, 16), bf[half:].reshape(half // 16, 16)], 1).reshape(2 * half)
+    z = a.double() @ wf.double().t() + bf.double()
+    ref = z[:, :half] * F.gelu(z[:, half:])
+    got = o.gemm_nt(a.to(DEV), o.split_weights(wi.to(DEV)), bias=bi.to(DEV), act=o.ACT_GEGLU)
+    assert got.shape == (M, half) and rel_err(got, ref) < 1e-6
+    got2 = o.gemm_nt(a.to(DEV), wi.to(DEV), bias=bi.to(DEV), act=o.ACT_GEGLU)  # plain float32 W, split in the kernel
+    assert rel_err(got2, ref) < 3e-6
