@@ -86,6 +86,18 @@ inline int grid_for(int64_t n) {
     return (int)g;
 }
 
+// out[0:n] = out[n:2n] = in[0:n] in 16-byte chunks: the CFG shared prefix duplicates a tensor for the two text conditionings
+// (stable_diffusion_dual_unet.py:1045 torch.cat([latents] * 2), applied where the two halves first differ).  One read, two
+// writes per chunk; the runtime's generic device-to-device copy took 2 x 83 us for the 2 x 10.5 MB of a level-0 tensor inside
+// the two-stream pipeline (rocprofv3, profiles/r03_*), this kernel streams it at the HBM rate.
+__global__ __launch_bounds__(kThreads) void dup_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = in[i];
+        out[i] = v;
+        out[n + i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -150,6 +162,16 @@ int gmd_embedding_lookup(const int32_t* ids, const void* table, const void* pos,
         embedding_kernel<T><<<grid, kThreads, 0, s>>>(ids, (const T*)table, (const T*)pos, (T*)out, rows, T_, C, vocab);
     });
     GMD_CHECK_LAUNCH("gmd_embedding_lookup");
+    return GMD_OK;
+}
+
+int gmd_dup_batch(const void* in, void* out, int64_t bytes, gmd_stream_t stream) {
+    GMD_REQUIRE(bytes >= 0 && bytes % 16 == 0, "gmd_dup_batch: byte count must be a non-negative multiple of 16");
+    if (bytes == 0) return GMD_OK;
+    GMD_REQUIRE(in && out && gmd_aligned16(in) && gmd_aligned16(out), "gmd_dup_batch: null or unaligned pointer");
+    const int64_t n = bytes / 16;
+    dup_kernel<<<grid_for(n), kThreads, 0, (hipStream_t)stream>>>((const uint4*)in, (uint4*)out, n);
+    GMD_CHECK_LAUNCH("gmd_dup_batch");
     return GMD_OK;
 }
 

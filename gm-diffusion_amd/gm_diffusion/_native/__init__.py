@@ -43,6 +43,8 @@ SIGNATURES = {
     "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, I, P, L, P],
     "gmd_gemm_colstats_plan": [I, I, I, I, I, L, I],
     "gmd_split_weights": [P, P, L, L, L, P],
+    "gmd_ff_geglu_fused_supported": [I, L, I],
+    "gmd_ff_geglu_fused": [P, P, P, P, P, P, P, I, L, I, P],
     "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, L, P, F, P, I, P, L, P],
     "gmd_attention": [P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],
     "gmd_softmax_rows": [P, L, P, I, L, L, I, F, I, P],
@@ -58,6 +60,7 @@ SIGNATURES = {
     "gmd_concat_channels": [P, I, P, I, P, I, L, P],
     "gmd_embedding_lookup": [P, P, P, P, I, L, I, I, I, P],
     "gmd_cast": [P, I, P, I, L, P],
+    "gmd_dup_batch": [P, P, L, P],
 }
 _RESTYPES = {"gmd_last_error": c_char_p}
 

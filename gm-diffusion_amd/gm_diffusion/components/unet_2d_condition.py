@@ -517,10 +517,8 @@ class UNet2DConditionModel(_HipModule):
 
     @staticmethod
     def _dup_batch(t):
-        """[B, ...] -> [2B, ...] (two device-to-device copies; memory plumbing only)."""
-        out = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        out[: t.shape[0]].copy_(t)
-        out[t.shape[0]:].copy_(t)
+        """[B, ...] -> [2B, ...]: both halves equal to ``t`` (gmd_dup_batch: one read, two writes)."""
+        out = ops.dup_batch(t.contiguous())
         st = getattr(t, "_colstats", None)
         if st is not None and not isinstance(st, list):  # producer statistics are per 64-row block, sample-major: duplicate alike
             out._colstats = (torch.cat([st[0], st[0]], 0), st[1])
@@ -554,11 +552,14 @@ class UNet2DConditionModel(_HipModule):
         h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h)
         # GEGLU feed-forward
         n3 = ops.layernorm(h, *t["norm3"])
-        if t["ff1_fused"]:
-            f = ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1], act=ops.ACT_GEGLU)  # h * gelu(g) formed in the GEMM epilogue
+        if t["ff1_fused"] and ops.ff_fused_ok(n3, C):  # the whole feed-forward in one launch: [tokens, 4C] never reaches HBM
+            h = ops.ff_geglu_fused(n3, t["ff1"][0], t["ff1"][1], t["ff2"][0], t["ff2"][1], h)
         else:
-            f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
-        h = ops.gemm_nt(f, t["ff2"][0], bias=t["ff2"][1], residual=h)
+            if t["ff1_fused"]:
+                f = ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1], act=ops.ACT_GEGLU)  # h * gelu(g) formed in the GEMM epilogue
+            else:
+                f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
+            h = ops.gemm_nt(f, t["ff2"][0], bias=t["ff2"][1], residual=h)
         y = ops.gemm_nt(h, t["pout"][0], bias=t["pout"][1], residual=x.view(B * N, C), colstats=self._wants_colstats(H, W))
         return ops.carry_colstats(y.view(B, N, C), y)
 

@@ -21,7 +21,7 @@ from . import profiling
 from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F16, GMD_F32, GMD_F32S, GMD_F32SW, HipExtensionError, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows", "set_f32_mode", "f32_split", "split_weights", "scale_weight", "split_attention_ok",
+    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows", "set_f32_mode", "f32_split", "split_weights", "scale_weight", "split_attention_ok", "ff_fused_ok", "ff_geglu_fused", "dup_batch",
     "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "groupnorm_split", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
@@ -285,6 +285,37 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     return out
 
 
+# The GEGLU feed-forward as one launch (csrc/ff_fused.hip) where the kernel is instantiated; GMD_FUSED_FF=0 keeps the two
+# GEMM launches (A/B measurements, tests).
+USE_FUSED_FF = os.environ.get("GMD_FUSED_FF", "1") != "0"
+# One 128-row workgroup per CU: below ~7/8 of the chip's 256 CUs the two tiled GEMM launches (two workgroups per CU, 512+ tiles)
+# are faster -- tools/bench_ff.py: M = 32768 90 vs 124 us, M = 16384 (half the chip) 82 vs 67 us.
+FUSED_FF_MIN_ROWS = int(os.environ.get("GMD_FUSED_FF_MIN_ROWS", str(224 * 128)))
+
+
+def ff_fused_ok(x, C, min_rows=None):
+    return (USE_FUSED_FF and is_half(x.dtype) and x.dim() == 2 and x.shape[0] >= (FUSED_FF_MIN_ROWS if min_rows is None else min_rows) and
+            bool(lib().gmd_ff_geglu_fused_supported(dtype_code(x.dtype), x.shape[0], C)))
+
+
+def ff_geglu_fused(x, w1i, b1i, w2, b2, residual):
+    """``(value * gelu(gate)) @ w2.T + b2 + residual`` with ``[value | gate] = x @ w1i.T + b1i`` (interleaved rows)."""
+    _dev(x, w1i, b1i, w2, b2, residual)
+    M, C = x.shape
+    if w1i.shape != (8 * C, C) or w2.shape != (C, 4 * C) or residual.shape != x.shape or not (x.dtype == w1i.dtype == w2.dtype == residual.dtype):
+        raise HipExtensionError("ff_geglu_fused: operand shapes / dtypes inconsistent")
+    y = torch.empty_like(x)
+    tm = profiling.active()
+    tm = tm if tm is not None and tm.wants("gemm_nt") else None
+    t0 = tm.begin() if tm else None
+    check(lib().gmd_ff_geglu_fused(_ptr(x), _ptr(w1i), _ptr(_f32(b1i, "b1")), _ptr(w2), _ptr(_f32(b2, "b2")), _ptr(residual), _ptr(y),
+                                   dtype_code(x.dtype), M, C, _stream()), "gmd_ff_geglu_fused")
+    if tm:  # both products' algorithmic FLOPs; bytes: x, residual, y once + the weights
+        es = x.element_size()
+        tm.end("gemm_nt", 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C, (3 * M * C + 12 * C * C) * es, t0)
+    return y
+
+
 def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, upsample=False, pad_mode=0, out_dtype=None,
             colstats=False):
     """x: [B, H*W, Cin]; w: [Cout, 9*Cin] (tap-major); returns ([B, Hout*Wout, Cout], Hout, Wout)."""
@@ -513,6 +544,19 @@ def concat_channels(a, b):
     sa, sb = getattr(a, "_colstats", None), getattr(b, "_colstats", None)
     if sa is not None and sb is not None and not isinstance(sa, list) and not isinstance(sb, list):
         out._colstats = [sa, sb]  # a following GroupNorm reads the two producers' statistics side by side
+    return out
+
+
+def dup_batch(t):
+    """[B, ...] -> [2B, ...] with both halves equal to ``t`` (one read, two writes; the CFG duplication of a shared-prefix tensor)."""
+    _dev(t)
+    out = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    nbytes = t.numel() * t.element_size()
+    if nbytes % 16 or os.environ.get("GMD_DUP_KERNEL", "1") == "0":  # (the switch: A/B measurements only)
+        out[: t.shape[0]].copy_(t)
+        out[t.shape[0]:].copy_(t)
+        return out
+    check(lib().gmd_dup_batch(_ptr(t), _ptr(out), nbytes, _stream()), "gmd_dup_batch")
     return out
 
 

@@ -214,6 +214,17 @@ int gmd_split_weights(const float* W, void* out, int64_t N, int64_t K, int64_t l
  * convolution pass M = B*Hout*Wout, N = Cout, K = 9*Cin. */
 int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket);
 
+/* GEGLU feed-forward of a BasicTransformerBlock in ONE launch (diffusers FeedForward: ff.net.0 = GEGLU(C -> 4C), ff.net.2 =
+ * Linear(4C -> C); the reference reaches it through UNet2DConditionModel at stable_diffusion_dual_unet.py:1052, 1083):
+ *   Y = (value * gelu_erf(gate)) @ W2^T + b2 + residual,  [value | gate] = X @ W1i^T + b1i
+ * X, residual, Y: [M, C] of `dtype` (16-bit); W1i [8C, C] / b1i [8C]: ff.net.0.proj with value / gate rows interleaved in
+ * 16-row groups (the layout of GMD_ACT_GEGLU); W2 [C, 4C], b2 [C].  The [M, 4C] GEGLU tensor stays on chip.  Instantiated
+ * where a 128-row block's output fits the register file: gmd_ff_geglu_fused_supported() says whether (dtype, M, C) is
+ * (C == 320, M % 128 == 0); elsewhere use gmd_gemm_nt(GMD_ACT_GEGLU) + gmd_gemm_nt. */
+int gmd_ff_geglu_fused_supported(int dtype, int64_t M, int C);
+int gmd_ff_geglu_fused(const void* X, const void* W1i, const float* b1i, const void* W2, const float* b2, const void* residual,
+                       void* Y, int dtype, int64_t M, int C, gmd_stream_t stream);
+
 /* 3x3 convolution, padding 1, as an implicit GEMM over channels-last data.
  * X: [B,Hin,Win,Cin]; Wt: [Cout, 9*Cin] with k = (ky*3+kx)*Cin + c; Y: [B,Hout,Wout,Cout].
  * stride 1 or 2 (Downsample2D: Hout = (Hin+2-3)/2+1); upsample=1 fuses nearest-2x
@@ -289,6 +300,10 @@ int gmd_concat_channels(const void* A, int Ca, const void* Bm, int Cb, void* out
  * exclude (checked there), rows = B*T. */
 int gmd_embedding_lookup(const int32_t* ids, const void* table, const void* pos, void* out, int dtype,
                          int64_t rows, int T, int C, int vocab, gmd_stream_t stream);
+/* out[0:bytes] = out[bytes:2*bytes] = in[0:bytes] (bytes % 16 == 0): the batch duplication of classifier-free guidance
+ * (stable_diffusion_dual_unet.py:1045-1047 torch.cat([latents] * 2)) applied to an activation where the two conditionings
+ * first differ (the CFG shared prefix of UNet2DConditionModel.forward_packed) */
+int gmd_dup_batch(const void* in, void* out, int64_t bytes, gmd_stream_t stream);
 /* elementwise cast between F32 and BF16 */
 int gmd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, gmd_stream_t stream);
 

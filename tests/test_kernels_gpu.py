@@ -925,3 +925,34 @@ def test_attention_partial_last_tile_never_reads_poisoned_memory(dtype, D, Nk):
     got = o.attention(q.to(DEV), kfull.to(DEV), vt.to(DEV), H, Nk, D ** -0.5)
     assert torch.isfinite(got.float()).all()
     assert rel_err(got.float(), ref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("M", [128, 4096, 16384])
+def test_ff_geglu_fused_matches_two_gemms_and_float64(dtype, M):
+    """csrc/ff_fused.hip: the whole GEGLU feed-forward of a level-0 transformer block in one launch (the [tokens, 4C] tensor
+    stays on chip) against the two-launch path it replaces (same operands, same dtype) and a float64 reference."""
+    o = ops()
+    C = 320
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, C, generator=g).to(dtype)
+    res = torch.randn(M, C, generator=g).to(dtype)
+    wf = (torch.randn(8 * C, C, generator=g) / math.sqrt(C)).to(dtype)
+    bf = torch.randn(8 * C, generator=g) * 0.2
+    w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).to(dtype)
+    b2 = torch.randn(C, generator=g) * 0.2
+    half = 4 * C
+    wi = torch.stack([wf[:half].reshape(half // 16, 16, -1), wf[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1).contiguous()
+    bi = torch.stack([bf[:half].reshape(half // 16, 16), bf[half:].reshape(half // 16, 16)], 1).reshape(2 * half).contiguous()
+    z = x.double() @ wf.double().t() + bf.double()
+    hmid = z[:, :half] * F.gelu(z[:, half:])
+    ref = hmid @ w2.double().t() + b2.double() + res.double()
+    xd, rd, wid_, bid, w2d, b2d = x.to(DEV), res.to(DEV), wi.to(DEV), bi.to(DEV), w2.to(DEV), b2.to(DEV)
+    assert o.ff_fused_ok(xd, C, min_rows=0)
+    got = o.ff_geglu_fused(xd, wid_, bid, w2d, b2d, rd)
+    two = o.gemm_nt(o.gemm_nt(xd, wid_, bias=bid, act=o.ACT_GEGLU), w2d, bias=b2d, residual=rd)
+    t = 1.5e-2 if dtype == torch.bfloat16 else 2e-3
+    assert rel_err(got.float(), ref) < t and rel_err(two.float(), ref) < t
+    assert rel_err(got.float(), two.float()) < t  # both round H to the 16-bit type once; only the summation order differs
+    assert not o.ff_fused_ok(xd[:100], C, min_rows=0) and not o.ff_fused_ok(torch.zeros(128, 640, dtype=dtype, device=DEV), 640, min_rows=0)
+    assert o.ff_fused_ok(xd, C) == (M >= o.FUSED_FF_MIN_ROWS)  # the product path takes it only where it fills the chip

@@ -9,8 +9,11 @@ from gm_diffusion import hip_ops as ops
 B, H, W, ci, co = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (8, 64, 64, 320, 320))]
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 g = torch.Generator().manual_seed(0)
-x = torch.randn(B, H * W, ci, generator=g).bfloat16().cuda()
-w = (torch.randn(co, 9 * ci, generator=g) * 0.02).bfloat16().cuda()
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[os.environ.get("GMD_ONE_DTYPE", "bf16")]  # f32 = split path, pre-split W
+x = torch.randn(B, H * W, ci, generator=g).to(DT).cuda()
+w = (torch.randn(co, 9 * ci, generator=g) * 0.02).to(DT).cuda()
+if DT == torch.float32:
+    w = ops.split_weights(w)
 b = torch.randn(co, generator=g).cuda()
 for _ in range(reps):
     ops.conv3x3(x, w, B, H, W, bias=b)

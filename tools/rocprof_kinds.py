@@ -20,12 +20,12 @@ for s, e, name in rows:
         if last_kind:  # belongs to the GEMM / conv launch it completes: add time, not a launch
             agg[last_kind][1] += d
         continue
-    g = re.search(r"gemm_(?:ring|bf16|f32)_kernel<(?:[^,<>]+, )?(true|false)", name)  # <[element type, ]CONV, ...>
+    g = re.search(r"gemm_(?:ring|bf16|f32|split)_kernel<(?:[^,<>]+, )?(true|false)", name)  # <[element type, ]CONV, ...>
     if g and g.group(1) == "true":
         last_kind = "conv3x3"
-    elif g:
+    elif g or "ff_fused_kernel" in name:
         last_kind = "gemm_nt"
-    elif "attn_fwd_kernel" in name or "attn40_kernel" in name:
+    elif "attn_fwd_kernel" in name or "attn40_kernel" in name or "attn_split_kernel" in name:
         last_kind = "attention"
     else:
         last_kind = None
