@@ -21,12 +21,16 @@ for s, e, name in rows:
             agg[last_kind][1] += d
         continue
     g = re.search(r"gemm_(?:ring|bf16|f32|split)_kernel<(?:[^,<>]+, )?(true|false)", name)  # <[element type, ]CONV, ...>
+    # arithmetic family: the default bench command also runs the float32 pipelines (tolerance_path, drift reference), whose
+    # launches must not be averaged into the 16-bit kinds
+    fam = (" [f32 split]" if ("gemm_split_kernel" in name or "attn_split_kernel" in name) else " [f32 exact]" if "gemm_f32_kernel" in name
+           else " [f16]" if "_Float16" in name else "")
     if g and g.group(1) == "true":
-        last_kind = "conv3x3"
+        last_kind = "conv3x3" + fam
     elif g or "ff_fused_kernel" in name:
-        last_kind = "gemm_nt"
+        last_kind = "gemm_nt" + fam
     elif "attn_fwd_kernel" in name or "attn40_kernel" in name or "attn_split_kernel" in name:
-        last_kind = "attention"
+        last_kind = "attention" + fam
     else:
         last_kind = None
         m = re.search(r"(?:::)?(\w+)\s*(?:<|\()", name.replace("void ", "").replace("(anonymous namespace)::", ""))
