@@ -284,8 +284,9 @@ def main():
     # same short run.
     drift = None
     tol_path = None
-    want_tol = not a.no_tolerance_path and not tiny and a.dtype in ("bf16", "f16")
-    want_drift = not a.no_drift and not tiny and a.dtype in ("bf16", "f16")
+    # (single-GPU runs only, like cpu_baseline: in a multi-GPU run the other ranks would wait at the final barrier for rank 0)
+    want_tol = not a.no_tolerance_path and not tiny and a.dtype in ("bf16", "f16") and world == 1
+    want_drift = not a.no_drift and not tiny and a.dtype in ("bf16", "f16") and world == 1
     if rank == 0 and (want_tol or want_drift):
         from gm_diffusion import hip_ops
 

@@ -126,3 +126,84 @@ def test_pipeline_fullsize_graph_equals_eager_and_tail(sd15, res, batch, steps):
     assert torch.equal(o.discretize_u16(q1), q1)
     qf, codes = o.discretize_u16(out["hdr_file"], codes=True)
     assert torch.equal(qf, q1) and torch.equal(codes.cpu().to(torch.int32).float() / 65535.0, q1.cpu())  # true division on the host
+
+
+# ---------------------------------------------------------------------------------------------
+# the float32 pipeline on the matrix cores (three float16 products per float32 product) at full size
+# ---------------------------------------------------------------------------------------------
+def test_split_attention_16k_tokens_properties():
+    """float32 self-attention of the 1024x1024 workload (csrc/attention_split.hip): 16384 tokens, 8 heads of d = 40."""
+    o = _ops()
+    prev = o.set_f32_mode("split")
+    try:
+        B, H, D, N = 1, 8, 40, 16384
+        C = H * D
+        g = torch.Generator().manual_seed(2)
+        q = torch.randn(B, N, C, generator=g).to(DEV)
+        k = torch.randn(B, N, C, generator=g).to(DEV)
+        scale = D ** -0.5
+        out = o.attention(q, k, torch.ones(B, C, N, device=DEV), H, N, scale)
+        assert float((out - 1).abs().max()) < 8e-6  # 16384-term float32 row sums
+        v1, v2 = torch.randn(B, C, N, generator=g).to(DEV), torch.randn(B, C, N, generator=g).to(DEV)
+        a1, a2, a12 = o.attention(q, k, v1, H, N, scale), o.attention(q, k, v2, H, N, scale), o.attention(q, k, v1 + v2, H, N, scale)
+        assert rel(a12, a1 + a2) < 3e-6
+        sl = slice(9000, 9064)
+        qf, kf = q[:, sl].double().view(B, 64, H, D).transpose(1, 2), k.double().view(B, N, H, D).transpose(1, 2)
+        ref = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ v1.double().view(B, H, D, N).transpose(-1, -2)).transpose(1, 2).reshape(B, 64, C)
+        assert rel(a1[:, sl], ref) < 3e-6
+    finally:
+        o.set_f32_mode(prev)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", [(8, 64, 64, 320, 320), (2, 128, 128, 640, 320), (1, 512, 512, 128, 128)])
+def test_split_conv3x3_fullsize_linearity_and_exact_kernel(B, H, W, ci, co):
+    o = _ops()
+    prev = o.set_f32_mode("split")
+    try:
+        g = torch.Generator().manual_seed(ci + H)
+        x1, x2 = torch.randn(B, H * W, ci, generator=g).to(DEV), torch.randn(B, H * W, ci, generator=g).to(DEV)
+        w = o.split_weights((torch.randn(co, 9 * ci, generator=g) * (9 * ci) ** -0.5).to(DEV))
+        y1, y2, y12 = (o.conv3x3(x, w, B, H, W)[0] for x in (x1, x2, x1 + x2))
+        assert torch.isfinite(y12).all() and rel(y12, y1 + y2) < 2e-6
+        xs = torch.roll(x1.view(B, H, W, ci), 1, dims=2).reshape(B, H * W, ci).contiguous()
+        ys = o.conv3x3(xs, w, B, H, W)[0].view(B, H, W, co)
+        assert torch.equal(ys[:, 2:-2, 3:-2], y1.view(B, H, W, co)[:, 2:-2, 2:-3])  # shift equivariance: the same sums in the same order
+    finally:
+        o.set_f32_mode(prev)
+
+
+@pytest.mark.parametrize("res,batch,steps", [(512, 4, 3), (1024, 8, 2)])
+def test_split_pipeline_fullsize_graph_equals_eager(res, batch, steps):
+    """BASELINE configs[1] / configs[3] shapes in float32 on the matrix cores: captured-graph, eager and two-stream runs are
+    bit-identical, everything finite, the decode tail consistent with Eq. 1."""
+    from gm_diffusion import hdr
+    from gm_diffusion.components import AutoencoderKL, PNDMScheduler, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
+
+    o = _ops()
+    prev = o.set_f32_mode("split")
+    try:
+        dt = torch.float32
+        pipe = StableDiffusionDualUNetPipeline(
+            vae=AutoencoderKL().init_random(9, device=DEV).to(DEV, dt), text_encoder=None, tokenizer=None,
+            unet=UNet2DConditionModel(in_channels=4).init_random(7, device=DEV).to(DEV, dt),
+            gm_unet=UNet2DConditionModel(in_channels=8).init_random(8, device=DEV).to(DEV, dt),
+            scheduler=PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1,
+                                    set_alpha_to_one=False), safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+        pipe.set_progress_bar_config(disable=True)
+        h = res // 8
+        g = torch.Generator().manual_seed(res)
+        pe, ne = torch.randn(batch, 77, 768, generator=g).to(DEV), torch.randn(batch, 77, 768, generator=g).to(DEV)
+        lat = torch.randn(batch, 4, h, h, generator=g).to(DEV)
+        kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=res, width=res, num_inference_steps=steps,
+                  guidance_scale=7.5, output_type="latent")
+        a = pipe(**kw)
+        pipe.use_hip_graphs, pipe.overlap_streams = False, False
+        e = pipe(**kw)
+        assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1])
+        assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+        out = hdr.decode_to_hdr(pipe.vae, a[0], a[1], qmax=99.0, want=("sdr", "gm", "hdr"))
+        assert out["hdr"].shape == (batch, res, res, 3) and torch.isfinite(out["hdr"]).all()
+        assert torch.equal(o.apply_gm_to_sdr(out["gm"], out["sdr"], qmax=99.0, eps=1 / 64, clamp=False), out["hdr"])
+    finally:
+        o.set_f32_mode(prev)
