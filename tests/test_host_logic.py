@@ -488,3 +488,36 @@ def test_predrawn_scheduler_noise_is_capped_and_ordered():
         assert P._predraw_step_noise([s1, s2], ts, shape, torch.Generator().manual_seed(5), "cpu") is None
     finally:
         P.PREDRAW_NOISE_BYTES = old
+
+
+def test_float32_contraction_mode_selection():
+    """Which dtype code a contraction gets (hip_ops._contract_code): float32 tensors go to the matrix cores as three float16
+    products (GMD_F32S, or GMD_F32SW for a pre-split weight) in mode 'split' when K is a multiple of 32, to the exact FMA
+    kernels otherwise; 16-bit tensors never meet a pre-split weight; the mode switch validates its argument."""
+    from gm_diffusion import hip_ops as ops
+    from gm_diffusion._native import GMD_BF16, GMD_F16, GMD_F32, GMD_F32S, GMD_F32SW, HipExtensionError
+
+    a, w = torch.zeros(4, 64), torch.zeros(8, 64)
+    prev = ops.set_f32_mode("split")
+    try:
+        assert ops.f32_split() and ops._contract_code(a, w, 64) == GMD_F32S
+        assert ops._contract_code(a[:, :48], w[:, :48], 48) == GMD_F32  # K % 32 != 0: exact kernel
+        ws = torch.zeros(8, 64)
+        ws._split = True
+        assert ops._contract_code(a, ws, 64) == GMD_F32SW
+        assert ops._contract_code(a.bfloat16(), w.bfloat16(), 64) == GMD_BF16 and ops._contract_code(a.half(), w.half(), 64) == GMD_F16
+        with pytest.raises(HipExtensionError):
+            ops._contract_code(a.half(), ws, 64)
+        assert ops.set_f32_mode("exact") == "split" and not ops.f32_split()
+        assert ops._contract_code(a, w, 64) == GMD_F32
+        assert ops._contract_code(a, ws, 64) == GMD_F32SW  # a model prepared in split mode keeps its pre-split weights
+        assert not ops.split_attention_ok(torch.float32, 40)
+        ops.set_f32_mode("split")
+        assert ops.split_attention_ok(torch.float32, 40) and not ops.split_attention_ok(torch.float32, 64)
+        assert not ops.split_attention_ok(torch.bfloat16, 40)
+        with pytest.raises(HipExtensionError):
+            ops.set_f32_mode("fast")
+        with pytest.raises(HipExtensionError):
+            ops.split_weights(torch.zeros(8, 64))  # host tensor: no CPU fallback
+    finally:
+        ops.set_f32_mode(prev)

@@ -20,7 +20,8 @@ for s, e, name in rows:
         if last_kind:  # belongs to the GEMM / conv launch it completes: add time, not a launch
             agg[last_kind][1] += d
         continue
-    g = re.search(r"gemm_(?:ring|bf16|f32|split)_kernel<(?:[^,<>]+, )?(true|false)", name)  # <[element type, ]CONV, ...>
+    # <[element type, ]CONV, ...> for the 16-bit kernels, <CONV, ...> for the float32 ones
+    g = re.search(r"gemm_(?:split|f32)_kernel<(true|false)", name) or re.search(r"gemm_(?:ring|bf16)_kernel<[^,<>]+, (true|false)", name)
     # arithmetic family: the default bench command also runs the float32 pipelines (tolerance_path, drift reference), whose
     # launches must not be averaged into the 16-bit kinds
     fam = (" [f32 split]" if ("gemm_split_kernel" in name or "attn_split_kernel" in name) else " [f32 exact]" if "gemm_f32_kernel" in name
