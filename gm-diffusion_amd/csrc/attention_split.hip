@@ -357,10 +357,11 @@ int gmd_launch_attention_split(const void* Q, const void* K, const void* Vt, voi
     hipError_t e;
     switch (D) {
         case 40: e = launch_attn_split<40>(p, B, stream); break;
+        case 64: e = launch_attn_split<64>(p, B, stream); break;  // SDXL: every level has heads of 64
         case 80: e = launch_attn_split<80>(p, B, stream); break;
         case 160: e = launch_attn_split<160>(p, B, stream); break;
         default:
-            gmd_set_error("gmd_attention: float32 (split) attention is instantiated for head dims 40, 80, 160 (got %d)", D);
+            gmd_set_error("gmd_attention: float32 (split) attention is instantiated for head dims 40, 64, 80, 160 (got %d)", D);
             return GMD_ERR_UNSUPPORTED;
     }
     if (e != hipSuccess) {

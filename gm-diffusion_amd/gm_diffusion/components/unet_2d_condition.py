@@ -41,6 +41,18 @@ SD15_UNET_DEFAULTS = dict(
     block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1, mid_block_scale_factor=1,
     act_fn="silu", norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=768, attention_head_dim=8,
     time_cond_proj_dim=None,
+    # SDXL-style options (BASELINE.json configs[4]; the reference has no such path -- SURVEY.md §7 "SDXL / fp8" -- so these
+    # follow diffusers' UNet2DConditionModel config names and are checked against the oracle's restatement only): all off for SD-1.5
+    transformer_layers_per_block=1, use_linear_projection=False, addition_embed_type=None, addition_time_embed_dim=None,
+    projection_class_embeddings_input_dim=None,
+)
+
+# stabilityai/stable-diffusion-xl-base-1.0 unet/config.json as restated in oracle/unet.py (2,567,463,684 parameters)
+SDXL_UNET_CONFIG = dict(
+    block_out_channels=(320, 640, 1280), down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), transformer_layers_per_block=(1, 2, 10),
+    attention_head_dim=(5, 10, 20), cross_attention_dim=2048, use_linear_projection=True, addition_embed_type="text_time",
+    addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816, sample_size=128,
 )
 
 
@@ -208,12 +220,12 @@ class UNet2DConditionModel(_HipModule):
         # generate_hdr.py:103-105 rewrites `num_attention_heads` to the legacy `attention_head_dim` name
         if "num_attention_heads" in config and config["num_attention_heads"] is not None:
             cfg["attention_head_dim"] = config["num_attention_heads"]
-        if isinstance(cfg["attention_head_dim"], (list, tuple)):
-            if len(set(cfg["attention_head_dim"])) != 1:
-                raise NotImplementedError("per-block attention_head_dim")
+        if isinstance(cfg["attention_head_dim"], (list, tuple)) and len(set(cfg["attention_head_dim"])) == 1:
             cfg["attention_head_dim"] = cfg["attention_head_dim"][0]
         if cfg["act_fn"] != "silu" or cfg["time_cond_proj_dim"] is not None or cfg["center_input_sample"]:
-            raise NotImplementedError("only the SD-1.5 UNet flavour is implemented (silu, no time_cond_proj, no centering)")
+            raise NotImplementedError("only silu / no time_cond_proj / no centering UNets are implemented (SD-1.5, SDXL)")
+        if cfg["addition_embed_type"] not in (None, "text_time"):
+            raise NotImplementedError(f"addition_embed_type={cfg['addition_embed_type']!r}")
         self._unknown_config = unknown
         self.register_to_config(**cfg)
         self._init_module()
@@ -222,6 +234,7 @@ class UNet2DConditionModel(_HipModule):
         self._capturing = False
         self._transformers = []
         self._graphs = {}
+        self._aug = {}  # text_time conditioning: persistent [B, temb] buffers, rewritten in place by set_added_cond
 
     # ------------------------------------------------------------------------------------------
     # structure
@@ -231,12 +244,13 @@ class UNet2DConditionModel(_HipModule):
         c = self.config
         ch = list(c.block_out_channels)
         n = c.layers_per_block
+        heads, depth = self._per_level(c.attention_head_dim), self._per_level(c.transformer_layers_per_block)
         downs, cout = [], ch[0]
         for i, t in enumerate(c.down_block_types):
             cin, cout = cout, ch[i]
             downs.append(dict(res=[(cin if j == 0 else cout, cout) for j in range(n)], attn=t.startswith("CrossAttn"),
-                              down=i != len(ch) - 1, c=cout))
-        rev = list(reversed(ch))
+                              down=i != len(ch) - 1, c=cout, heads=heads[i], depth=depth[i]))
+        rev, rheads, rdepth = list(reversed(ch)), list(reversed(heads)), list(reversed(depth))
         ups, cout = [], rev[0]
         for i, t in enumerate(c.up_block_types):
             cprev, cout = cout, rev[i]
@@ -246,8 +260,16 @@ class UNet2DConditionModel(_HipModule):
                 skip = cin if j == n else cout
                 rin = cprev if j == 0 else cout
                 res.append((rin + skip, cout))
-            ups.append(dict(res=res, attn=t.startswith("CrossAttn"), up=i != len(ch) - 1, c=cout))
+            ups.append(dict(res=res, attn=t.startswith("CrossAttn"), up=i != len(ch) - 1, c=cout, heads=rheads[i], depth=rdepth[i]))
         return downs, ups
+
+    def _per_level(self, v):
+        """An int or one value per resolution level (``attention_head_dim`` = heads, ``transformer_layers_per_block``)."""
+        L = len(self.config.block_out_channels)
+        v = list(v) if isinstance(v, (list, tuple)) else [v] * L
+        if len(v) != L:
+            raise ValueError(f"expected one value per level ({L}), got {v}")
+        return v
 
     def expected_keys(self):
         c = self.config
@@ -272,33 +294,40 @@ class UNet2DConditionModel(_HipModule):
             if ci != co:
                 conv(k + ".conv_shortcut", co, ci, 1)
 
-        def transformer(k, d):
-            norm(k + ".norm", d); conv(k + ".proj_in", d, d, 1); conv(k + ".proj_out", d, d, 1)
-            b = k + ".transformer_blocks.0"
-            for nm in ("norm1", "norm2", "norm3"):
-                norm(f"{b}.{nm}", d)
-            for a, kd in (("attn1", d), ("attn2", cross)):
-                lin(f"{b}.{a}.to_q", d, d, False); lin(f"{b}.{a}.to_k", d, kd, False); lin(f"{b}.{a}.to_v", d, kd, False)
-                lin(f"{b}.{a}.to_out.0", d, d)
-            lin(f"{b}.ff.net.0.proj", 8 * d, d); lin(f"{b}.ff.net.2", d, 4 * d)
+        def transformer(k, d, depth):
+            norm(k + ".norm", d)
+            if c.use_linear_projection:
+                lin(k + ".proj_in", d, d); lin(k + ".proj_out", d, d)
+            else:
+                conv(k + ".proj_in", d, d, 1); conv(k + ".proj_out", d, d, 1)
+            for n_ in range(depth):
+                b = f"{k}.transformer_blocks.{n_}"
+                for nm in ("norm1", "norm2", "norm3"):
+                    norm(f"{b}.{nm}", d)
+                for a, kd in (("attn1", d), ("attn2", cross)):
+                    lin(f"{b}.{a}.to_q", d, d, False); lin(f"{b}.{a}.to_k", d, kd, False); lin(f"{b}.{a}.to_v", d, kd, False)
+                    lin(f"{b}.{a}.to_out.0", d, d)
+                lin(f"{b}.ff.net.0.proj", 8 * d, d); lin(f"{b}.ff.net.2", d, 4 * d)
 
         conv("conv_in", ch[0], c.in_channels, 3)
         lin("time_embedding.linear_1", temb, ch[0]); lin("time_embedding.linear_2", temb, temb)
+        if c.addition_embed_type == "text_time":
+            lin("add_embedding.linear_1", temb, c.projection_class_embeddings_input_dim); lin("add_embedding.linear_2", temb, temb)
         downs, ups = self._layout()
         for i, blk in enumerate(downs):
             for j, (ci, co) in enumerate(blk["res"]):
                 resnet(f"down_blocks.{i}.resnets.{j}", ci, co)
                 if blk["attn"]:
-                    transformer(f"down_blocks.{i}.attentions.{j}", co)
+                    transformer(f"down_blocks.{i}.attentions.{j}", co, blk["depth"])
             if blk["down"]:
                 conv(f"down_blocks.{i}.downsamplers.0.conv", blk["c"], blk["c"], 3)
-        resnet("mid_block.resnets.0", ch[-1], ch[-1]); transformer("mid_block.attentions.0", ch[-1])
+        resnet("mid_block.resnets.0", ch[-1], ch[-1]); transformer("mid_block.attentions.0", ch[-1], downs[-1]["depth"])
         resnet("mid_block.resnets.1", ch[-1], ch[-1])
         for i, blk in enumerate(ups):
             for j, (ci, co) in enumerate(blk["res"]):
                 resnet(f"up_blocks.{i}.resnets.{j}", ci, co)
                 if blk["attn"]:
-                    transformer(f"up_blocks.{i}.attentions.{j}", co)
+                    transformer(f"up_blocks.{i}.attentions.{j}", co, blk["depth"])
             if blk["up"]:
                 conv(f"up_blocks.{i}.upsamplers.0.conv", blk["c"], blk["c"], 3)
         norm("conv_norm_out", ch[0]); conv("conv_out", c.out_channels, ch[0], 3)
@@ -389,50 +418,62 @@ class UNet2DConditionModel(_HipModule):
                 r["sc"] = self._lin(k + ".conv_shortcut")
             return r
 
-        def transformer(k):
-            b = k + ".transformer_blocks.0"
-            t = dict(norm=self._norm(k + ".norm"), pin=self._lin(k + ".proj_in"), pout=self._lin(k + ".proj_out"))
-            for nm in ("norm1", "norm2", "norm3"):
-                t[nm] = self._norm(f"{b}.{nm}")
-            q1, k1 = self._raw[f"{b}.attn1.to_q.weight"], self._raw[f"{b}.attn1.to_k.weight"]
-            t["qk1"] = self._wt(torch.cat([q1, k1], 0))  # fused [2C, C] projection
-            t["v1"] = self._wa(self._raw[f"{b}.attn1.to_v.weight"])
-            t["o1"] = self._lin(f"{b}.attn1.to_out.0")
-            t["q2"] = self._lin(f"{b}.attn2.to_q", False)[0]
-            t["k2"] = self._lin(f"{b}.attn2.to_k", False)[0]
-            t["v2"] = self._wa(self._raw[f"{b}.attn2.to_v.weight"])
-            t["o2"] = self._lin(f"{b}.attn2.to_out.0")
-            if ops.is_half(self._dtype) or self._split_mode():
-                # fused GEGLU epilogue: interleave value / gate rows in groups of 16 so both land in the same MFMA lane
-                wf, bf = self._raw[f"{b}.ff.net.0.proj.weight"], self._raw[f"{b}.ff.net.0.proj.bias"]
-                half = wf.shape[0] // 2
-                wi = torch.stack([wf[:half].reshape(half // 16, 16, -1), wf[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1)
-                bi = torch.stack([bf[:half].reshape(half // 16, 16), bf[half:].reshape(half // 16, 16)], 1).reshape(2 * half)
-                t["ff1"] = (self._wt(wi), self._f32(bi))
-                t["ff1_fused"] = True
-            else:
-                t["ff1"] = self._lin(f"{b}.ff.net.0.proj")
-                t["ff1_fused"] = False
-            t["ff2"] = self._lin(f"{b}.ff.net.2")
-            t["key"] = k
-            self._transformers.append(t)
+        def transformer(k, heads, depth):
+            """GroupNorm + proj_in / proj_out around ``depth`` BasicTransformerBlocks (1 for SD-1.5; 1 / 2 / 10 per level for SDXL)."""
+            t = dict(norm=self._norm(k + ".norm"), pin=self._lin(k + ".proj_in"), pout=self._lin(k + ".proj_out"), heads=heads, blocks=[])
+            for n_ in range(depth):
+                b = f"{k}.transformer_blocks.{n_}"
+                blk = dict(heads=heads)
+                for nm in ("norm1", "norm2", "norm3"):
+                    blk[nm] = self._norm(f"{b}.{nm}")
+                q1, k1 = self._raw[f"{b}.attn1.to_q.weight"], self._raw[f"{b}.attn1.to_k.weight"]
+                blk["qk1"] = self._wt(torch.cat([q1, k1], 0))  # fused [2C, C] projection
+                blk["v1"] = self._wa(self._raw[f"{b}.attn1.to_v.weight"])
+                blk["o1"] = self._lin(f"{b}.attn1.to_out.0")
+                blk["q2"] = self._lin(f"{b}.attn2.to_q", False)[0]
+                blk["k2"] = self._lin(f"{b}.attn2.to_k", False)[0]
+                blk["v2"] = self._wa(self._raw[f"{b}.attn2.to_v.weight"])
+                blk["o2"] = self._lin(f"{b}.attn2.to_out.0")
+                if ops.is_half(self._dtype) or self._split_mode():
+                    # fused GEGLU epilogue: interleave value / gate rows in groups of 16 so both land in the same MFMA lane
+                    wf, bf = self._raw[f"{b}.ff.net.0.proj.weight"], self._raw[f"{b}.ff.net.0.proj.bias"]
+                    half = wf.shape[0] // 2
+                    wi = torch.stack([wf[:half].reshape(half // 16, 16, -1), wf[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1)
+                    bi = torch.stack([bf[:half].reshape(half // 16, 16), bf[half:].reshape(half // 16, 16)], 1).reshape(2 * half)
+                    blk["ff1"] = (self._wt(wi), self._f32(bi))
+                    blk["ff1_fused"] = True
+                else:
+                    blk["ff1"] = self._lin(f"{b}.ff.net.0.proj")
+                    blk["ff1_fused"] = False
+                blk["ff2"] = self._lin(f"{b}.ff.net.2")
+                blk["key"] = b
+                self._transformers.append(blk)  # every block has its own cross-attention K / V^T of the text tokens
+                t["blocks"].append(blk)
             return t
 
         downs, ups = self._layout()
+        if c.addition_embed_type == "text_time":
+            wa = self._raw["add_embedding.linear_1.weight"]  # K = pooled text width + 6 sinusoids: zero-padded to the kernels' K multiple
+            self._add_k = _pad_to(wa.shape[1], self._kmul())
+            wp = torch.zeros(wa.shape[0], self._add_k)
+            wp[:, : wa.shape[1]] = wa
+            w["add1"] = (self._wt(wp), self._f32(self._raw["add_embedding.linear_1.bias"]))
+            w["add2"] = self._lin("add_embedding.linear_2")
         w["down"] = []
         for i, blk in enumerate(downs):
             e = dict(res=[resnet(f"down_blocks.{i}.resnets.{j}") for j in range(len(blk["res"]))])
             if blk["attn"]:
-                e["attn"] = [transformer(f"down_blocks.{i}.attentions.{j}") for j in range(len(blk["res"]))]
+                e["attn"] = [transformer(f"down_blocks.{i}.attentions.{j}", blk["heads"], blk["depth"]) for j in range(len(blk["res"]))]
             if blk["down"]:
                 e["ds"] = self._conv3(f"down_blocks.{i}.downsamplers.0.conv")
             w["down"].append(e)
-        w["mid"] = dict(r0=resnet("mid_block.resnets.0"), a=transformer("mid_block.attentions.0"), r1=resnet("mid_block.resnets.1"))
+        w["mid"] = dict(r0=resnet("mid_block.resnets.0"), a=transformer("mid_block.attentions.0", downs[-1]["heads"], downs[-1]["depth"]),
+                        r1=resnet("mid_block.resnets.1"))
         w["up"] = []
         for i, blk in enumerate(ups):
             e = dict(res=[resnet(f"up_blocks.{i}.resnets.{j}") for j in range(len(blk["res"]))])
             if blk["attn"]:
-                e["attn"] = [transformer(f"up_blocks.{i}.attentions.{j}") for j in range(len(blk["res"]))]
+                e["attn"] = [transformer(f"up_blocks.{i}.attentions.{j}", blk["heads"], blk["depth"]) for j in range(len(blk["res"]))]
             if blk["up"]:
                 e["us"] = self._conv3(f"up_blocks.{i}.upsamplers.0.conv")
             w["up"].append(e)
@@ -442,6 +483,7 @@ class UNet2DConditionModel(_HipModule):
         w["te_all"] = (self._wt(torch.cat(te_w, 0)), self._f32(torch.cat(te_b, 0)))
         self._kv_cache = {}
         self._graphs = {}
+        self._aug = {}
         self._t_dev = torch.zeros(1, dtype=torch.float32, device=self._device)
         return w
 
@@ -467,7 +509,7 @@ class UNet2DConditionModel(_HipModule):
         return H * W >= 1024 and (H * W) % 64 == 0
 
     def _self_attention(self, t, n1, B, N, C):
-        heads = self.config.attention_head_dim
+        heads = t["heads"]
         d = C // heads
         scale = d ** -0.5
         qk = ops.gemm_nt(n1, t["qk1"]).view(B, N, 2 * C)
@@ -526,13 +568,21 @@ class UNet2DConditionModel(_HipModule):
 
     def _transformer(self, t, x, B, H, W, ehs, cfg_dup=False):
         """``cfg_dup``: x holds the B UNIQUE samples of a classifier-free-guidance pair whose two halves differ only in the
-        text conditioning; everything up to the cross-attention query is computed once, then duplicated (returns 2B rows)."""
+        text conditioning; everything up to the first cross-attention query is computed once, then duplicated (returns 2B rows)."""
         C = x.shape[-1]
         N = H * W
-        heads = self.config.attention_head_dim
-        d = C // heads
         h = ops.groupnorm(x, B, self.config.norm_num_groups, t["norm"][0], t["norm"][1], 1e-6, silu=False)
-        h = ops.gemm_nt(h.view(B * N, C), t["pin"][0], bias=t["pin"][1])
+        h = ops.gemm_nt(h.view(B * N, C), t["pin"][0], bias=t["pin"][1])  # conv1x1 and nn.Linear proj_in are the same GEMM on tokens
+        for blk in t["blocks"]:
+            h, x, B = self._transformer_block(blk, h, x, B, N, C, ehs, cfg_dup)
+            cfg_dup = False  # the first cross-attention has duplicated the batch
+        y = ops.gemm_nt(h, t["pout"][0], bias=t["pout"][1], residual=x.view(B * N, C), colstats=self._wants_colstats(H, W))
+        return ops.carry_colstats(y.view(B, N, C), y)
+
+    def _transformer_block(self, t, h, x, B, N, C, ehs, cfg_dup):
+        """One BasicTransformerBlock on tokens ``h`` [B*N, C]; returns (h, x, B) -- x / B change when ``cfg_dup`` duplicates."""
+        heads = t["heads"]
+        d = C // heads
         # self-attention
         n1 = ops.layernorm(h, *t["norm1"])
         o = self._self_attention(t, n1, B, N, C)
@@ -560,8 +610,7 @@ class UNet2DConditionModel(_HipModule):
             else:
                 f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
             h = ops.gemm_nt(f, t["ff2"][0], bias=t["ff2"][1], residual=h)
-        y = ops.gemm_nt(h, t["pout"][0], bias=t["pout"][1], residual=x.view(B * N, C), colstats=self._wants_colstats(H, W))
-        return ops.carry_colstats(y.view(B, N, C), y)
+        return h, x, B
 
     def set_timestep(self, timestep):
         """Write the timestep into the device scalar read by the embedding kernel (kept outside any
@@ -579,7 +628,53 @@ class UNet2DConditionModel(_HipModule):
     def supports_cfg_shared(self):
         """True when the first down block has a transformer (SD-1.5): the prefix shared by a CFG pair ends at its
         cross-attention."""
-        return self.config.down_block_types[0].startswith("CrossAttn")
+        return self.config.down_block_types[0].startswith("CrossAttn") and self.config.addition_embed_type is None
+
+    def set_added_cond(self, added_cond_kwargs, B):
+        """SDXL micro-conditioning (diffusers ``get_aug_embed`` for addition_embed_type "text_time"): sinusoid of every scalar of
+        ``time_ids`` [B, 6] concatenated behind the pooled text embedding ``text_embeds`` [B, P], through add_embedding.linear_1 ->
+        SiLU -> linear_2; the result is ADDED to the time embedding in every forward.  Constant over the denoising loop: computed
+        once per call here (eager, HIP kernels) into a persistent [B, temb] buffer that captured graphs keep reading."""
+        self._ensure()
+        c = self.config
+        if c.addition_embed_type != "text_time":
+            if added_cond_kwargs:
+                raise NotImplementedError("this UNet has no addition embedding (added_cond_kwargs given)")
+            return None
+        if not added_cond_kwargs or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
+            raise ValueError("this UNet needs added_cond_kwargs = {'text_embeds': [B, P], 'time_ids': [B, 6]} (addition_embed_type 'text_time')")
+        te, ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+        if te.shape[0] != B or ids.shape[0] != B or not te.is_cuda:
+            raise ValueError(f"added_cond_kwargs must hold {B} device rows (got {tuple(te.shape)}, {tuple(ids.shape)})")
+        d = c.addition_time_embed_dim
+        P = te.shape[1]
+        if P + ids.shape[1] * d != c.projection_class_embeddings_input_dim:
+            raise ValueError("text_embeds / time_ids widths do not match projection_class_embeddings_input_dim")
+        key = (te.data_ptr(), te._version, ids.data_ptr(), ids._version, B)
+        ent = self._aug.get(B)
+        if ent is not None and ent["key"] == key:
+            return ent["aug"]
+        if self._capturing:
+            raise HipExtensionError("the added conditioning must be prepared (set_added_cond) before graph capture")
+        cat = torch.zeros((B, self._add_k), dtype=self._dtype, device=self._device)
+        tex = te.contiguous()
+        if tex.dtype != self._dtype:
+            tex = ops.cast(tex if tex.dtype in (torch.float32, torch.bfloat16, torch.float16) else tex.float(), self._dtype)
+        cat[:, :P].copy_(tex)
+        flat = ids.to(self._device, torch.float32).contiguous().view(-1)  # (a [B, 6] table of image sizes / crops given by the caller)
+        for i in range(flat.numel()):  # one [1, d] sinusoid per scalar: the timestep-embedding kernel, reading the scalar on the device
+            b, j = divmod(i, ids.shape[1])
+            cat[b, P + j * d:P + (j + 1) * d].copy_(ops.timestep_embedding(flat[i:i + 1], 1, d, self._dtype, c.flip_sin_to_cos, c.freq_shift)[0])
+        w = self._w
+        a1 = ops.gemm_nt(cat, w["add1"][0], bias=w["add1"][1], act=ops.ACT_SILU)
+        aug = ops.gemm_nt(a1, w["add2"][0], bias=w["add2"][1])
+        if ent is None:
+            ent = self._aug[B] = dict(aug=aug)
+        else:
+            ent["aug"].copy_(aug)  # in place: a captured graph keeps reading this buffer
+        ent["key"] = key
+        ent["src"] = (te, ids)  # keep the sources alive while the key is valid
+        return ent["aug"]
 
     def forward_packed(self, x, B, H, W, encoder_hidden_states, cfg_shared=False):
         """x: packed channels-last input [B, H*W, cin_pad]; the timestep must already be in ``_t_dev``.
@@ -601,7 +696,13 @@ class UNet2DConditionModel(_HipModule):
             raise HipExtensionError("cfg_shared needs an even batch and a transformer in the first down block")
         te = ops.timestep_embedding(self._t_dev, B, c.block_out_channels[0], self._dtype, c.flip_sin_to_cos, c.freq_shift)
         te = ops.gemm_nt(te, w["te1"][0], bias=w["te1"][1], act=ops.ACT_SILU)
-        temb = ops.gemm_nt(te, w["te2"][0], bias=w["te2"][1], act=ops.ACT_SILU)  # = silu(temb): the only use of temb
+        aug = None
+        if c.addition_embed_type == "text_time":  # emb = time_embedding(t) + add_embedding(...): the sum goes through the SiLU below
+            ent = self._aug.get(B)
+            if ent is None:
+                raise HipExtensionError("this UNet needs its added conditioning first: set_added_cond(added_cond_kwargs, batch)")
+            aug = ent["aug"]
+        temb = ops.gemm_nt(te, w["te2"][0], bias=w["te2"][1], residual=aug, act=ops.ACT_SILU)  # = silu(temb): the only use of temb
         temb = ops.gemm_nt(temb, w["te_all"][0], bias=w["te_all"][1], out_dtype=torch.float32)  # [B, sum(Cout)] f32
         Bc = B // 2 if cfg_shared else B  # rows currently carried (the unique half until the first cross-attention)
         x, _, _ = ops.conv3x3(x, w["conv_in"][0], Bc, H, W, bias=w["conv_in"][1], colstats=self._wants_colstats(H, W))
@@ -644,6 +745,8 @@ class UNet2DConditionModel(_HipModule):
         ``update_context`` -- both outside the graph, so one capture serves every step and every prompt."""
         self._ensure()
         self.update_context(ehs)
+        if self.config.addition_embed_type is not None and B not in self._aug:
+            raise HipExtensionError("set_added_cond(added_cond_kwargs, batch) must precede graphed_forward for this UNet")
         key = (B, H, W, tuple(ehs.shape), bool(cfg_shared))
         g = self._graphs.get(key)
         if g is not None:
@@ -705,8 +808,8 @@ class UNet2DConditionModel(_HipModule):
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
                  added_cond_kwargs=None, return_dict=True, **kwargs):
-        if timestep_cond is not None or added_cond_kwargs:
-            raise NotImplementedError("timestep_cond / added_cond_kwargs are not part of the SD-1.5 GM-Diffusion path")
+        if timestep_cond is not None:
+            raise NotImplementedError("timestep_cond is not part of the GM-Diffusion path")
         self._ensure()
         first = sample[0] if isinstance(sample, (tuple, list)) else sample
         B, _, H, W = first.shape
@@ -717,6 +820,7 @@ class UNet2DConditionModel(_HipModule):
         if ehs.shape[0] != B:
             raise ValueError(f"encoder_hidden_states batch {ehs.shape[0]} != sample batch {B}")
         self.set_timestep(timestep)
+        self.set_added_cond(added_cond_kwargs, B)
         out = self.forward_packed(x, B, H, W, ehs)
         if not return_dict:
             return (out,)

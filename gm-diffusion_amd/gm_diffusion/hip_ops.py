@@ -353,7 +353,7 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     return y, ho, wo
 
 
-SPLIT_ATTENTION_HEAD_DIMS = (40, 80, 160)  # float32 flash kernel (attention_split.hip): the UNet's head dims
+SPLIT_ATTENTION_HEAD_DIMS = (40, 64, 80, 160)  # float32 flash kernel (attention_split.hip): SD-1.5's head dims and SDXL's 64
 
 
 def split_attention_ok(dtype, d):
@@ -374,7 +374,7 @@ def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False):
     o = torch.empty((B, nq, hd), dtype=q.dtype, device=q.device)
     if q.dtype == torch.float32:
         if not (f32_split() and d in SPLIT_ATTENTION_HEAD_DIMS):
-            raise HipExtensionError("attention: float32 runs on the split (three float16 products) kernel, head dims 40/80/160, "
+            raise HipExtensionError("attention: float32 runs on the split (three float16 products) kernel, head dims 40/64/80/160, "
                                     "in F32_MODE 'split' only; the exact float32 path composes gemm_nt + softmax_rows")
         code = GMD_F32S
     else:

@@ -41,6 +41,21 @@ SD15_UNET_CONFIG = dict(
     sample_size=64,
     up_block_types=["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"],
     time_cond_proj_dim=None,
+    # SDXL-style options (BASELINE config 5; no reference behaviour exists for them -- SURVEY.md 7 "SDXL / fp8"): all off for SD-1.5
+    transformer_layers_per_block=1,   # int, or one depth per down block (the up blocks use the reversed list, the mid block the last)
+    use_linear_projection=False,      # Transformer2DModel proj_in / proj_out as nn.Linear on tokens instead of conv1x1
+    addition_embed_type=None,         # "text_time": micro-conditioning (time_ids) + pooled text embedding added to the time embedding
+    addition_time_embed_dim=None,
+    projection_class_embeddings_input_dim=None,
+)
+
+# diffusers' config of stabilityai/stable-diffusion-xl-base-1.0 (unet/config.json), restated from knowledge of diffusers 0.33
+# [3P-memory]; pinned here only by its published parameter count, 2,567,463,684 (tests/test_oracle_models.py)
+SDXL_UNET_CONFIG = dict(
+    block_out_channels=[320, 640, 1280], down_block_types=["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+    up_block_types=["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"], transformer_layers_per_block=[1, 2, 10],
+    attention_head_dim=[5, 10, 20], cross_attention_dim=2048, use_linear_projection=True, addition_embed_type="text_time",
+    addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816, sample_size=128,
 )
 
 
@@ -148,22 +163,31 @@ class BasicTransformerBlock(nn.Module):
 
 
 class Transformer2DModel(nn.Module):
-    """SD-1.5 flavour: conv1x1 projections (use_linear_projection=False), GN eps 1e-6."""
+    """SD-1.5 flavour: conv1x1 projections (use_linear_projection=False), one block, GN eps 1e-6.  SDXL flavour: nn.Linear
+    projections applied on tokens, ``depth`` BasicTransformerBlocks."""
 
-    def __init__(self, dim, heads, cross_dim, groups=32):
+    def __init__(self, dim, heads, cross_dim, groups=32, depth=1, linear=False):
         super().__init__()
+        self.linear = linear
         self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
-        self.proj_in = nn.Conv2d(dim, dim, 1)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, heads, cross_dim)])
-        self.proj_out = nn.Conv2d(dim, dim, 1)
+        self.proj_in = nn.Linear(dim, dim) if linear else nn.Conv2d(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, heads, cross_dim) for _ in range(depth)])
+        self.proj_out = nn.Linear(dim, dim) if linear else nn.Conv2d(dim, dim, 1)
 
     def forward(self, x, context):
         B, C, H, W = x.shape
-        h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h = self.norm(x)
+        if self.linear:
+            h = self.proj_in(h.permute(0, 2, 3, 1).reshape(B, H * W, C))
+        else:
+            h = self.proj_in(h).permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
-        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-        return self.proj_out(h) + x
+        if self.linear:
+            h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        else:
+            h = self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
+        return h + x
 
 
 class Downsample2D(nn.Module):
@@ -185,11 +209,11 @@ class Upsample2D(nn.Module):
 
 
 class DownBlock(nn.Module):
-    def __init__(self, cin, cout, temb, n, heads, cross_dim, attn, down, groups, eps):
+    def __init__(self, cin, cout, temb, n, heads, cross_dim, attn, down, groups, eps, depth=1, linear=False):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups, eps) for i in range(n)])
         if attn:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(n)])
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups, depth, linear) for _ in range(n)])
         self.has_attn = attn
         if down:
             self.downsamplers = nn.ModuleList([Downsample2D(cout)])
@@ -209,10 +233,10 @@ class DownBlock(nn.Module):
 
 
 class MidBlock(nn.Module):
-    def __init__(self, c, temb, heads, cross_dim, groups, eps):
+    def __init__(self, c, temb, heads, cross_dim, groups, eps, depth=1, linear=False):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, groups, eps), ResnetBlock2D(c, c, temb, groups, eps)])
-        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, cross_dim, groups)])
+        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, cross_dim, groups, depth, linear)])
 
     def forward(self, x, temb, ctx):
         x = self.resnets[0](x, temb)
@@ -221,7 +245,7 @@ class MidBlock(nn.Module):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, cin, cout, cprev, temb, n, heads, cross_dim, attn, up, groups, eps):
+    def __init__(self, cin, cout, cprev, temb, n, heads, cross_dim, attn, up, groups, eps, depth=1, linear=False):
         super().__init__()
         res = []
         for i in range(n):
@@ -230,7 +254,7 @@ class UpBlock(nn.Module):
             res.append(ResnetBlock2D(rin + skip, cout, temb, groups, eps))
         self.resnets = nn.ModuleList(res)
         if attn:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups) for _ in range(n)])
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cross_dim, groups, depth, linear) for _ in range(n)])
         self.has_attn = attn
         if up:
             self.upsamplers = nn.ModuleList([Upsample2D(cout)])
@@ -253,24 +277,32 @@ class UNet2DConditionModel(nn.Module):
         cfg.update(overrides)
         self.config = SimpleNamespace(**cfg)
         ch = cfg["block_out_channels"]
-        heads = cfg["attention_head_dim"]
+        L = len(ch)
+        as_list = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * L
+        heads = as_list(cfg["attention_head_dim"])           # legacy name: heads per level
+        depth = as_list(cfg["transformer_layers_per_block"])
+        linear = bool(cfg["use_linear_projection"])
         cross = cfg["cross_attention_dim"]
         groups, eps, n = cfg["norm_num_groups"], cfg["norm_eps"], cfg["layers_per_block"]
         temb = ch[0] * 4
         self.conv_in = nn.Conv2d(cfg["in_channels"], ch[0], 3, padding=1)
         self.time_embedding = TimestepEmbedding(ch[0], temb)
+        if cfg["addition_embed_type"] == "text_time":
+            self.add_embedding = TimestepEmbedding(cfg["projection_class_embeddings_input_dim"], temb)
+        elif cfg["addition_embed_type"] is not None:
+            raise NotImplementedError(cfg["addition_embed_type"])
         downs, cout = [], ch[0]
         for i, t in enumerate(cfg["down_block_types"]):
             cin, cout = cout, ch[i]
-            downs.append(DownBlock(cin, cout, temb, n, heads, cross, t.startswith("CrossAttn"), i != len(ch) - 1, groups, eps))
+            downs.append(DownBlock(cin, cout, temb, n, heads[i], cross, t.startswith("CrossAttn"), i != L - 1, groups, eps, depth[i], linear))
         self.down_blocks = nn.ModuleList(downs)
-        self.mid_block = MidBlock(ch[-1], temb, heads, cross, groups, eps)
-        rev = list(reversed(ch))
+        self.mid_block = MidBlock(ch[-1], temb, heads[-1], cross, groups, eps, depth[-1], linear)
+        rev, rheads, rdepth = list(reversed(ch)), list(reversed(heads)), list(reversed(depth))
         ups, cout = [], rev[0]
         for i, t in enumerate(cfg["up_block_types"]):
             cprev, cout = cout, rev[i]
-            cin = rev[min(i + 1, len(ch) - 1)]
-            ups.append(UpBlock(cin, cout, cprev, temb, n + 1, heads, cross, t.startswith("CrossAttn"), i != len(ch) - 1, groups, eps))
+            cin = rev[min(i + 1, L - 1)]
+            ups.append(UpBlock(cin, cout, cprev, temb, n + 1, rheads[i], cross, t.startswith("CrossAttn"), i != L - 1, groups, eps, rdepth[i], linear))
         self.up_blocks = nn.ModuleList(ups)
         self.conv_norm_out = nn.GroupNorm(groups, ch[0], eps=eps)
         self.conv_out = nn.Conv2d(ch[0], cfg["out_channels"], 3, padding=1)
@@ -290,6 +322,13 @@ class UNet2DConditionModel(nn.Module):
         t = timestep.reshape(-1).to(sample.device).expand(sample.shape[0])
         temb = timestep_embedding(t, self.config.block_out_channels[0], self.config.flip_sin_to_cos, self.config.freq_shift)
         temb = self.time_embedding(temb.to(sample.dtype))
+        if self.config.addition_embed_type == "text_time":
+            # diffusers get_aug_embed: sinusoid of every micro-conditioning scalar (time_ids [B, 6] -> [B, 6 * dim]) concatenated
+            # BEHIND the pooled text embedding, through add_embedding, added to the time embedding
+            text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+            te = timestep_embedding(time_ids.flatten(), self.config.addition_time_embed_dim, self.config.flip_sin_to_cos, self.config.freq_shift)
+            te = te.reshape(text_embeds.shape[0], -1)
+            temb = temb + self.add_embedding(torch.cat([text_embeds, te], dim=-1).to(sample.dtype))
         x = self.conv_in(sample)
         skips = [x]
         for blk in self.down_blocks:
@@ -307,3 +346,12 @@ def tiny_unet_config(in_channels=4):
     channels) used for pipeline parity tests that must finish in seconds on CPU."""
     return dict(in_channels=in_channels, block_out_channels=[64, 128, 128, 128], cross_attention_dim=64,
                 attention_head_dim=2, norm_num_groups=8, sample_size=8)
+
+
+def tiny_sdxl_unet_config(in_channels=4):
+    """A small UNet with every SDXL-style feature on (three levels, no attention at the first, transformer depths 1 / 2 / 3,
+    head dim 64, linear projections, text_time conditioning)."""
+    return dict(in_channels=in_channels, block_out_channels=[64, 128, 256], down_block_types=["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+                up_block_types=["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"], transformer_layers_per_block=[1, 2, 3],
+                attention_head_dim=[1, 2, 4], cross_attention_dim=128, use_linear_projection=True, addition_embed_type="text_time",
+                addition_time_embed_dim=32, projection_class_embeddings_input_dim=80 + 6 * 32, norm_num_groups=8, sample_size=16)

@@ -513,7 +513,7 @@ def test_float32_contraction_mode_selection():
         assert ops._contract_code(a, ws, 64) == GMD_F32SW  # a model prepared in split mode keeps its pre-split weights
         assert not ops.split_attention_ok(torch.float32, 40)
         ops.set_f32_mode("split")
-        assert ops.split_attention_ok(torch.float32, 40) and not ops.split_attention_ok(torch.float32, 64)
+        assert ops.split_attention_ok(torch.float32, 40) and ops.split_attention_ok(torch.float32, 64) and not ops.split_attention_ok(torch.float32, 32)
         assert not ops.split_attention_ok(torch.bfloat16, 40)
         with pytest.raises(HipExtensionError):
             ops.set_f32_mode("fast")

@@ -289,3 +289,74 @@ def test_cfg_shared_prefix_carries_producer_statistics_through_the_duplication(d
         assert not torch.equal(shared[:4], shared[4:])
         out[use] = shared
     assert rel_err(out[True], out[False]) < tol
+
+
+# ---------------------------------------------------------------------------------------------
+# SDXL-style UNet options (BASELINE.json configs[4]; no reference behaviour exists: parity is against the oracle's restatement)
+# ---------------------------------------------------------------------------------------------
+def _sdxl_inputs(ou, B, hw, L=9, seed=50):
+    c = ou.config
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, c.in_channels, hw, hw, generator=g)
+    ctx = torch.randn(B, L, c.cross_attention_dim, generator=g)
+    P = c.projection_class_embeddings_input_dim - 6 * c.addition_time_embed_dim
+    kw = dict(text_embeds=torch.randn(B, P, generator=g), time_ids=torch.tensor([[1024.0, 768, 0, 16, 1024, 768], [512, 512, 32, 0, 640, 512]][:B] * (B // 2 + 1))[:B])
+    return x, ctx, kw
+
+
+@pytest.mark.parametrize("dtype,mode,tol", [(torch.float32, "split", 3e-5), (torch.float32, "exact", 3e-5), (torch.bfloat16, "split", 4e-2),
+                                            (torch.float16, "split", 6e-3)])
+def test_tiny_sdxl_style_unet_forward(dtype, mode, tol):
+    """Three levels, no attention at the first, transformer depths 1 / 2 / 3 with heads of 64, nn.Linear projections, text_time
+    added conditioning -- HIP UNet against the oracle, eager and as a captured graph, with a second set of conditioning values
+    replayed through the same graph."""
+    from gm_diffusion import hip_ops as ops
+    from oracle import fixtures, unet as OU
+
+    prev = ops.set_f32_mode(mode)
+    try:
+        torch.manual_seed(77)
+        ou = OU.UNet2DConditionModel(**OU.tiny_sdxl_unet_config()).eval().requires_grad_(False)
+        hu = _hip_unet(ou, dtype)
+        x, ctx, kw = _sdxl_inputs(ou, 2, 16)
+        ref = ou(x, torch.tensor(333), encoder_hidden_states=ctx, added_cond_kwargs=kw)[0]
+        dkw = {k: v.to(DEV) for k, v in kw.items()}
+        got = hu(x.to(DEV), 333, encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=dkw, return_dict=False)[0]
+        assert got.shape == ref.shape and rel_err(got, ref) < tol, rel_err(got, ref)
+        # captured graph + in-place update of the conditioning
+        c = hu.prepare_context(ctx.to(DEV))
+        hu.set_timestep(333)
+        hu.set_added_cond(dkw, 2)
+        gph = hu.graphed_forward(2, 16, 16, c)
+        hu.pack_input(x.to(DEV), out=gph.x)
+        assert torch.equal(gph.replay(), got)
+        kw2 = dict(text_embeds=kw["text_embeds"] * 0.5, time_ids=kw["time_ids"] + 64.0)
+        ref2 = ou(x, torch.tensor(333), encoder_hidden_states=ctx, added_cond_kwargs=kw2)[0]
+        hu.set_added_cond({k: v.to(DEV) for k, v in kw2.items()}, 2)
+        got2 = gph.replay()
+        assert rel_err(got2, ref2) < tol and rel_err(got2, ref) > 0.05  # the new conditioning was really picked up by the replay
+        with pytest.raises(ValueError):
+            hu(x.to(DEV), 333, encoder_hidden_states=ctx.to(DEV), return_dict=False)  # the conditioning is mandatory for this UNet
+    finally:
+        ops.set_f32_mode(prev)
+
+
+def test_sdxl_unet_full_width_small_latent_vs_oracle():
+    """The SDXL-base UNet configuration at full width (2.57 G parameters: widths 320 / 640 / 1280, transformer depths 1 / 2 / 10,
+    20 heads of 64, 2048-wide text conditioning) on a 16x16 latent, float32 on the matrix cores and bfloat16, against the oracle."""
+    from oracle import unet as OU
+
+    torch.manual_seed(5)
+    torch.set_num_threads(16)
+    ou = OU.UNet2DConditionModel(**OU.SDXL_UNET_CONFIG).eval().requires_grad_(False)
+    x, ctx, kw = _sdxl_inputs(ou, 2, 16, L=77)
+    ref = ou(x, torch.tensor(601), encoder_hidden_states=ctx, added_cond_kwargs=kw)[0]
+    dkw = {k: v.to(DEV) for k, v in kw.items()}
+    hu = _hip_unet(ou, torch.float32)
+    got = hu(x.to(DEV), 601, encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=dkw, return_dict=False)[0]
+    assert rel_err(got, ref) < 5e-5, rel_err(got, ref)
+    del hu
+    torch.cuda.empty_cache()
+    hb = _hip_unet(ou, torch.bfloat16)
+    got_b = hb(x.to(DEV), 601, encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=dkw, return_dict=False)[0]
+    assert rel_err(got_b, ref) < 6e-2, rel_err(got_b, ref)

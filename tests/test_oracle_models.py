@@ -22,6 +22,44 @@ def test_sd15_unet_structure_matches_public_facts():
     assert sum(p.numel() for p in m8.parameters()) - n == 320 * 4 * 9
 
 
+def test_sdxl_unet_structure_matches_public_facts():
+    """BASELINE.json configs[4] names SDXL-base-1.0; the reference has no SDXL path, so the oracle's SDXL-style options are
+    pinned by public facts only: 2,567,463,684 parameters / 1680 state-dict entries, three levels, transformer depths
+    1 / 2 / 10 with heads of 64, linear projections, the text_time addition embedding (2816 -> 1280)."""
+    with torch.device("meta"):
+        m = OU.UNet2DConditionModel(**OU.SDXL_UNET_CONFIG)
+    assert sum(p.numel() for p in m.parameters()) == 2_567_463_684
+    sd = m.state_dict()
+    assert len(sd) == 1680
+    assert tuple(sd["add_embedding.linear_1.weight"].shape) == (1280, 2816)
+    assert tuple(sd["down_blocks.1.attentions.0.proj_in.weight"].shape) == (640, 640)  # nn.Linear, not conv1x1
+    assert "down_blocks.0.attentions.0.norm.weight" not in sd and "up_blocks.2.attentions.0.norm.weight" not in sd
+    assert len(m.mid_block.attentions[0].transformer_blocks) == 10 and len(m.up_blocks[0].attentions[2].transformer_blocks) == 10
+    assert len(m.down_blocks[1].attentions[0].transformer_blocks) == 2 and m.down_blocks[1].attentions[0].transformer_blocks[0].attn1.heads == 10
+    assert tuple(sd["mid_block.attentions.0.transformer_blocks.9.attn2.to_k.weight"].shape) == (1280, 2048)
+    # the product's key table describes the same network
+    from gm_diffusion.components.unet_2d_condition import SDXL_UNET_CONFIG, UNet2DConditionModel
+
+    want = UNet2DConditionModel(**SDXL_UNET_CONFIG).expected_keys()
+    assert set(want) == set(sd) and all(tuple(sd[k].shape) == tuple(v) for k, v in want.items())
+
+
+def test_sdxl_style_unet_added_conditioning_known_answer():
+    """text_time: with add_embedding zeroed the conditioning must vanish; time_ids enter through the sinusoid of each scalar."""
+    torch.manual_seed(0)
+    m = OU.UNet2DConditionModel(**OU.tiny_sdxl_unet_config()).eval().requires_grad_(False)
+    x, ctx = torch.randn(2, 4, 16, 16), torch.randn(2, 7, 128)
+    kw = dict(text_embeds=torch.randn(2, 80), time_ids=torch.tensor([[128.0, 96, 0, 8, 128, 96]] * 2))
+    a = m(x, torch.tensor(400), encoder_hidden_states=ctx, added_cond_kwargs=kw)[0]
+    kw2 = dict(kw, time_ids=kw["time_ids"] + 1.0)
+    assert (m(x, torch.tensor(400), encoder_hidden_states=ctx, added_cond_kwargs=kw2)[0] - a).abs().max() > 1e-6
+    for p in m.add_embedding.parameters():
+        p.zero_()
+    b = m(x, torch.tensor(400), encoder_hidden_states=ctx, added_cond_kwargs=kw)[0]
+    b2 = m(x, torch.tensor(400), encoder_hidden_states=ctx, added_cond_kwargs=kw2)[0]
+    assert torch.equal(b, b2)
+
+
 def test_sd15_vae_structure_matches_public_facts():
     with torch.device("meta"):
         v = OV.AutoencoderKL(with_encoder=True)
