@@ -62,7 +62,9 @@ def parse():
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
                     help="bf16 = BASELINE.json's metric; f16 = the reference's own half type, same kernels (side line); f32 = the parity path")
-    ap.add_argument("--unet", default="sd15", choices=["sd15", "tiny"], help="tiny = structural smoke config (not a valid bench)")
+    ap.add_argument("--unet", default="sd15", choices=["sd15", "tiny", "sdxl"],
+                    help="tiny = structural smoke config (not a valid bench); sdxl = SDXL-base-width dual UNets with text_time conditioning "
+                         "(BASELINE.json configs[4] shape; an extension -- the reference has no SDXL path; use with --res 1024 --inference-steps 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scheduler", default="pndm", choices=["pndm", "dpm++", "ddpm"],
                     help="pndm = BASELINE.json's metric; dpm++ / ddpm = the schedulers the reference's scripts construct (side measurements)")
@@ -180,6 +182,10 @@ def main():
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     tiny = a.unet == "tiny"
     ucfg = dict(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, attention_head_dim=2, norm_num_groups=8) if tiny else {}
+    if a.unet == "sdxl":
+        from gm_diffusion.components.unet_2d_condition import SDXL_UNET_CONFIG
+
+        ucfg = dict(SDXL_UNET_CONFIG)
     vcfg = dict(block_out_channels=(64, 64, 128, 128), norm_num_groups=8) if tiny else {}
 
     def make_sched():
@@ -223,8 +229,14 @@ def main():
         lat = torch.randn(total, 4, h, h, generator=torch.Generator("cpu").manual_seed(42))
     # the text hidden states travel in the model dtype (north star: "RCCL broadcast of text-encoder hidden states"; 15 MB at
     # batch 64 in bf16), rounded on rank 0 exactly as the UNet's prepare_context would round them; the latents stay float32
-    pos, neg, lat, _ = gdist.shard_prompt_batch(pos, neg, lat, total, (77, cross), (4, h, h), dtype, dev, force=use_dist)
+    pos, neg, lat, (lo, hi) = gdist.shard_prompt_batch(pos, neg, lat, total, (77, cross), (4, h, h), dtype, dev, force=use_dist)
     pos, neg, lat = pos.to(dev), neg.to(dev), lat.to(dev)
+    added = None
+    if a.unet == "sdxl":  # pooled text embeddings + micro-conditioning: seeded, generated alike on every rank, sliced like the prompts
+        ga = torch.Generator("cpu").manual_seed(2)
+        te, nte = torch.randn(total, 1280, generator=ga), torch.randn(total, 1280, generator=ga)
+        ids = torch.tensor([[float(a.res), float(a.res), 0.0, 0.0, float(a.res), float(a.res)]] * total)
+        added = dict(text_embeds=te[lo:hi].to(dev), negative_text_embeds=nte[lo:hi].to(dev), time_ids=ids[lo:hi].to(dev))
     unet._ensure(); gm_unet._ensure(); vae._ensure()
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
@@ -234,6 +246,8 @@ def main():
         kw = {}
         if a.scheduler == "ddpm":  # stochastic scheduler: one CPU generator shared by both scheduler steps (dual.py:1015)
             kw["generator"] = torch.Generator("cpu").manual_seed(gen_seed)
+        if added is not None:
+            kw["added_cond_kwargs"] = {k: v[: pe.shape[0]] for k, v in added.items()}
         sdr, gm = p(prompt_embeds=pe, negative_prompt_embeds=ne, latents=la, height=a.res, width=a.res,
                     num_inference_steps=n, guidance_scale=7.5, output_type="latent", **kw)
         return hdr.decode_to_hdr(v, sdr, gm, qmax=99.0, want=("sdr_u8", "gm_u8", "hdr", "hdr_u16")), sdr, gm
@@ -285,8 +299,8 @@ def main():
     drift = None
     tol_path = None
     # (single-GPU runs only, like cpu_baseline: in a multi-GPU run the other ranks would wait at the final barrier for rank 0)
-    want_tol = not a.no_tolerance_path and not tiny and a.dtype in ("bf16", "f16") and world == 1
-    want_drift = not a.no_drift and not tiny and a.dtype in ("bf16", "f16") and world == 1
+    want_tol = not a.no_tolerance_path and a.unet == "sd15" and a.dtype in ("bf16", "f16") and world == 1
+    want_drift = not a.no_drift and a.unet == "sd15" and a.dtype in ("bf16", "f16") and world == 1
     if rank == 0 and (want_tol or want_drift):
         from gm_diffusion import hip_ops
 
@@ -386,15 +400,15 @@ def main():
                                 "region (the timed region replays HIP graphs on two streams, which events cannot enter); chosen as the "
                                 "kind with the largest measured time over ALL instrumented kinds",
                     "share_of_instrumented_kernel_time": round(dom["ms"] / all_ms, 3)}
-        is_metric = a.scheduler == "pndm" and a.inference_steps == 50 and a.res == 512 and a.dtype == "bf16"
+        is_metric = a.scheduler == "pndm" and a.inference_steps == 50 and a.res == 512 and a.dtype == "bf16" and a.unet == "sd15"
         res = {
             "metric": ("HDR images/sec @ 512x512, 50 PNDM steps, dual-UNet" if is_metric
-                       else f"HDR images/sec @ {a.res}x{a.res}, {a.inference_steps} {a.scheduler} steps, dual-UNet, {a.dtype} [not the BASELINE metric]"),
+                       else f"HDR images/sec @ {a.res}x{a.res}, {a.inference_steps} {a.scheduler} steps, {a.unet} dual-UNet, {a.dtype} [not the BASELINE metric]"),
             "value": round(total * a.steps / elapsed, 4),
             "unit": "HDR images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"SD-v1-5 dual-UNet (SDR 4ch + GM 8ch) {a.res}x{a.res}, {a.inference_steps} {a.scheduler.upper()} steps "
+            "config": {"workload": f"{'SDXL-base-width' if a.unet == 'sdxl' else 'SD-v1-5'} dual-UNet (SDR 4ch + GM 8ch) {a.res}x{a.res}, {a.inference_steps} {a.scheduler.upper()} steps "
                                    f"({a.inference_steps + (1 if a.scheduler == 'pndm' else 0)} iterations), CFG 7.5, batch {B}/GPU, 2 VAE decodes + Eq.1 HDR tail"
                                    + (" [TINY smoke config - not a valid bench]" if tiny else ""),
                        "global_batch": total, "per_gpu_batch": B, "resolution": a.res, "inference_steps": a.inference_steps,

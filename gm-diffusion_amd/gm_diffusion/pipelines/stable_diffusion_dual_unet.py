@@ -67,6 +67,21 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                           requires_safety_checker, gm_unet=gm_unet)
         self._gm_streams = {}
 
+    @staticmethod
+    def _batched_added_cond(added_cond, do_cfg, device):
+        """(SDR UNet's, GM UNet's) added_cond_kwargs: [negative; positive] rows for the guidance batch, the positive rows for the
+        GM UNet (it runs the conditional half only, like its prompt embeddings); (None, None) without added conditioning."""
+        if not added_cond:
+            return None, None
+        pos = {k: added_cond[k].to(device) for k in ("text_embeds", "time_ids")}
+        if not do_cfg:
+            return pos, pos
+        if "negative_text_embeds" not in added_cond:
+            raise ValueError("classifier-free guidance with an SDXL-style UNet needs added_cond_kwargs['negative_text_embeds']")
+        neg_ids = added_cond.get("negative_time_ids", added_cond["time_ids"]).to(device)
+        return dict(text_embeds=torch.cat([added_cond["negative_text_embeds"].to(device), pos["text_embeds"]]),
+                    time_ids=torch.cat([neg_ids, pos["time_ids"]])), pos
+
     def _gm_stream(self, device):
         s = self._gm_streams.get(device)
         if s is None:
@@ -102,6 +117,11 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
         **kwargs,
     ):
         callback, callback_steps = self._pop_legacy_callbacks(kwargs)
+        # EXTENSION beyond the reference (which has no SDXL path: its added_cond_kwargs carry IP-adapter image embeddings only,
+        # stable_diffusion_gm.py:1022-1026): for UNets with addition_embed_type "text_time" the caller passes
+        # added_cond_kwargs = {"text_embeds", "time_ids"[, "negative_text_embeds", "negative_time_ids"]}; every other unknown
+        # keyword is ignored as in the reference
+        added_cond = kwargs.pop("added_cond_kwargs", None)
         if hasattr(callback_on_step_end, "tensor_inputs"):
             callback_on_step_end_tensor_inputs = callback_on_step_end.tensor_inputs
         height, width = self._default_hw(height, width)
@@ -143,11 +163,15 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
         self._num_timesteps = len(timesteps)
         self.gm_scheduler = copy.deepcopy(self.scheduler)  # dual.py:1037, after set_timesteps
 
+        sdr_added, gm_added = self._batched_added_cond(added_cond, do_cfg, latents.device)
         fused = self._use_fused(latents, self.unet, self.scheduler) and self._use_fused(latents, self.gm_unet, self.gm_scheduler)
         if fused:
             ctx = self.unet.prepare_context(prompt_embeds)
             gm_ctx = self.gm_unet.prepare_context(gm_prompt_embeds)
             h, w = latents.shape[-2:]
+            # constant over the loop: written once into the persistent buffers the (captured) forwards read
+            self.unet.set_added_cond(sdr_added, (2 if do_cfg else 1) * latents.shape[0])
+            self.gm_unet.set_added_cond(gm_added, latents.shape[0])
             # The GM UNet of step i needs only x0_i; the SDR UNet of step i+1 needs only latents_{i+1}: the two are
             # independent, so the GM stream runs on its own HIP stream one step behind the SDR stream and their
             # kernels overlap (the batch-B GM kernels alone cannot fill 256 CUs).
@@ -195,7 +219,7 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                     latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
                     gm_latents = self.gm_scheduler.scale_model_input(gm_latents, t)
                     sdr_noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, timestep_cond=None,
-                                               cross_attention_kwargs=self.cross_attention_kwargs, added_cond_kwargs=None,
+                                               cross_attention_kwargs=self.cross_attention_kwargs, added_cond_kwargs=sdr_added,
                                                return_dict=False)[0]
                     if do_cfg:
                         sdr_noise_pred_uncond, sdr_noise_pred_text = sdr_noise_pred.chunk(2)
@@ -210,7 +234,7 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                     latents = self.scheduler.step(sdr_noise_pred, t, latents, **extra_step_kwargs, return_dict=False)[0]
                     gm_latent_input = torch.cat([x0_latent, gm_latents], dim=1)
                     gm_noise_pred = self.gm_unet(gm_latent_input, t, encoder_hidden_states=gm_prompt_embeds, timestep_cond=None,
-                                                 cross_attention_kwargs=self.cross_attention_kwargs, added_cond_kwargs=None,
+                                                 cross_attention_kwargs=self.cross_attention_kwargs, added_cond_kwargs=gm_added,
                                                  return_dict=False)[0]
                     gm_latents = self.gm_scheduler.step(gm_noise_pred, t, gm_latents, **extra_step_kwargs, return_dict=False)[0]
 

@@ -61,11 +61,25 @@ def gm_loop(unet, scheduler, sdr_latent, prompt_embeds, negative_prompt_embeds, 
 
 @torch.no_grad()
 def dual_loop(unet, gm_unet, scheduler, prompt_embeds, negative_prompt_embeds, latents,
-              num_inference_steps=50, guidance_scale=7.5, guidance_rescale=0.0, generator=None, record=None):
-    """Joint SDR-UNet (CFG) + GM-UNet (conditional only, fed the SDR x0 prediction) loop (A2)."""
+              num_inference_steps=50, guidance_scale=7.5, guidance_rescale=0.0, generator=None, record=None, added_cond=None):
+    """Joint SDR-UNet (CFG) + GM-UNet (conditional only, fed the SDR x0 prediction) loop (A2).
+
+    ``added_cond`` (SDXL-style UNets only; the reference has no such path, BASELINE.json configs[4]): dict with ``text_embeds`` /
+    ``time_ids`` of the prompts and ``negative_text_embeds`` / ``negative_time_ids`` (default: the same time_ids) of the
+    unconditional half, batched exactly like the prompt embeddings: [negative; positive] for the SDR UNet, positive for the GM UNet."""
     do_cfg = guidance_scale > 1
     embeds = torch.cat([negative_prompt_embeds, prompt_embeds]) if do_cfg else prompt_embeds
     gm_embeds = embeds[negative_prompt_embeds.shape[0]:] if do_cfg else embeds  # vis.py:274
+    sdr_kw, gm_kw = {}, {}
+    if added_cond is not None:
+        pos = dict(text_embeds=added_cond["text_embeds"], time_ids=added_cond["time_ids"])
+        gm_kw = dict(added_cond_kwargs=pos)
+        if do_cfg:
+            neg_ids = added_cond.get("negative_time_ids", added_cond["time_ids"])
+            sdr_kw = dict(added_cond_kwargs=dict(text_embeds=torch.cat([added_cond["negative_text_embeds"], pos["text_embeds"]]),
+                                                 time_ids=torch.cat([neg_ids, pos["time_ids"]])))
+        else:
+            sdr_kw = dict(added_cond_kwargs=pos)
     scheduler.set_timesteps(num_inference_steps)
     latents = latents * scheduler.init_noise_sigma
     gm_latents = latents.clone()  # dual.py:1012: both streams start from the same noise
@@ -75,14 +89,14 @@ def dual_loop(unet, gm_unet, scheduler, prompt_embeds, negative_prompt_embeds, l
         x = torch.cat([latents] * 2) if do_cfg else latents
         x = scheduler.scale_model_input(x, t)
         gm_latents = gm_scheduler.scale_model_input(gm_latents, t)
-        eps = unet(x, t, encoder_hidden_states=embeds, return_dict=False)[0]
+        eps = unet(x, t, encoder_hidden_states=embeds, return_dict=False, **sdr_kw)[0]
         if do_cfg:
             eps = _cfg(eps, guidance_scale, guidance_rescale)
         a = scheduler.alphas_cumprod.to(eps.device)[t].view(-1, 1, 1, 1)  # dual.py:1072
         x0 = (latents - (1 - a).sqrt() * eps) / a.sqrt()  # pre-step latents
         latents = scheduler.step(eps, t, latents, **step_kw, return_dict=False)[0]
         gm_in = torch.cat([x0, gm_latents], dim=1)  # dual.py:1080
-        gm_eps = gm_unet(gm_in, t, encoder_hidden_states=gm_embeds, return_dict=False)[0]
+        gm_eps = gm_unet(gm_in, t, encoder_hidden_states=gm_embeds, return_dict=False, **gm_kw)[0]
         gm_latents = gm_scheduler.step(gm_eps, t, gm_latents, **step_kw, return_dict=False)[0]
         if record is not None:
             record.append((latents.clone(), gm_latents.clone()))

@@ -533,3 +533,39 @@ def test_gm_pipeline_baseline_config1_full_width_vs_cpu_oracle():
     d = rms(ob, ref)
     print(f"config-1 full width, bf16 final latent RMS vs fp32 oracle: {d:.3e}")
     assert d < 0.1 and torch.isfinite(ob).all()  # measured 8.1e-2 (deterministic kernels): a 25 % loss of bf16 accuracy would show
+
+
+@pytest.mark.parametrize("hip_graphs", [True, False])
+def test_dual_pipeline_with_sdxl_style_unets_matches_oracle(hip_graphs, f32_mode):
+    """BASELINE.json configs[4] names an SDXL dual-UNet; the reference has no SDXL path, so this is an extension checked against
+    the oracle's restatement only: both UNets SDXL-style (no attention at the first level, transformer depths 1 / 2 / 3, heads of
+    64, text_time conditioning), the conditioning batched like the prompt embeddings ([negative; positive] for the SDR UNet, the
+    positive rows for the GM UNet), PNDM, graphs + two streams and eager."""
+    from gm_diffusion.components import AutoencoderKL, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
+    from oracle import fixtures
+    from oracle import pipelines as OP
+    from oracle import schedulers as OS
+    from oracle import unet as OU
+
+    torch.manual_seed(11)
+    ou = OU.UNet2DConditionModel(**OU.tiny_sdxl_unet_config(4)).eval().requires_grad_(False)
+    og = OU.UNet2DConditionModel(**OU.tiny_sdxl_unet_config(8)).eval().requires_grad_(False)
+    pipe = StableDiffusionDualUNetPipeline(
+        vae=_hip(AutoencoderKL, fixtures.build_vae("tiny"), torch.float32), text_encoder=None, tokenizer=None,
+        unet=_hip(UNet2DConditionModel, ou, torch.float32), gm_unet=_hip(UNet2DConditionModel, og, torch.float32), scheduler=_pndm(),
+        safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    pipe.use_hip_graphs = pipe.overlap_streams = hip_graphs
+    g = torch.Generator().manual_seed(3)
+    pe, ne = torch.randn(2, 9, 128, generator=g), torch.randn(2, 9, 128, generator=g)
+    lat = torch.randn(2, 4, 16, 16, generator=g)
+    cond = dict(text_embeds=torch.randn(2, 80, generator=g), negative_text_embeds=torch.randn(2, 80, generator=g),
+                time_ids=torch.tensor([[128.0, 128, 0, 0, 128, 128], [128, 96, 8, 0, 128, 96]]))
+    rs, rg = OP.dual_loop(ou, og, OS.PNDMScheduler(), pe, ne, lat, 5, guidance_scale=6.0, added_cond=cond)
+    sdr, gm = pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+                   num_inference_steps=5, guidance_scale=6.0, output_type="latent", added_cond_kwargs={k: v.to(DEV) for k, v in cond.items()})
+    assert rms(sdr, rs) <= RMS_TOL and rms(gm, rg) <= RMS_TOL, (rms(sdr, rs), rms(gm, rg))
+    with pytest.raises(ValueError):  # the conditioning is not optional for such UNets
+        pipe(prompt_embeds=pe.to(DEV), negative_prompt_embeds=ne.to(DEV), latents=lat.to(DEV), height=128, width=128,
+             num_inference_steps=2, guidance_scale=6.0, output_type="latent")
