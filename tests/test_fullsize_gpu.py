@@ -207,3 +207,36 @@ def test_split_pipeline_fullsize_graph_equals_eager(res, batch, steps):
         assert torch.equal(o.apply_gm_to_sdr(out["gm"], out["sdr"], qmax=99.0, eps=1 / 64, clamp=False), out["hdr"])
     finally:
         o.set_f32_mode(prev)
+
+
+def test_sdxl_width_dual_pipeline_1024_graph_equals_eager():
+    """BASELINE.json configs[4] shape at its per-GPU share (SDXL-base-width dual UNets with text_time conditioning, 1024x1024,
+    batch 4, bf16; an extension -- the reference has no SDXL path): captured-graph + two-stream and eager runs bit-identical,
+    finite latents, each sample independent of the batch it runs in."""
+    from gm_diffusion.components import AutoencoderKL, PNDMScheduler, UNet2DConditionModel
+    from gm_diffusion.components.unet_2d_condition import SDXL_UNET_CONFIG
+    from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
+
+    dt = torch.bfloat16
+    pipe = StableDiffusionDualUNetPipeline(
+        vae=AutoencoderKL().init_random(9, device=DEV).to(DEV, dt), text_encoder=None, tokenizer=None,
+        unet=UNet2DConditionModel(in_channels=4, **SDXL_UNET_CONFIG).init_random(7, device=DEV).to(DEV, dt),
+        gm_unet=UNet2DConditionModel(in_channels=8, **SDXL_UNET_CONFIG).init_random(8, device=DEV).to(DEV, dt),
+        scheduler=PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1,
+                                set_alpha_to_one=False), safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    B, res = 4, 1024
+    g = torch.Generator().manual_seed(12)
+    pe, ne = torch.randn(B, 77, 2048, generator=g).to(DEV), torch.randn(B, 77, 2048, generator=g).to(DEV)
+    lat = torch.randn(B, 4, res // 8, res // 8, generator=g).to(DEV)
+    cond = dict(text_embeds=torch.randn(B, 1280, generator=g).to(DEV), negative_text_embeds=torch.randn(B, 1280, generator=g).to(DEV),
+                time_ids=torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B).to(DEV))
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=res, width=res, num_inference_steps=2, guidance_scale=5.0,
+              output_type="latent", added_cond_kwargs=cond)
+    a = pipe(**kw)
+    pipe.use_hip_graphs, pipe.overlap_streams = False, False
+    e = pipe(**kw)
+    assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1]) and torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+    one = pipe(prompt_embeds=pe[1:2], negative_prompt_embeds=ne[1:2], latents=lat[1:2], height=res, width=res, num_inference_steps=2,
+               guidance_scale=5.0, output_type="latent", added_cond_kwargs={k: v[1:2] for k, v in cond.items()})
+    assert rel(a[0][1:2].float(), one[0].float()) < 3e-2 and rel(a[1][1:2].float(), one[1].float()) < 3e-2
