@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __re
         const int g = g0 + (int)threadIdx.x / 8, sub = threadIdx.x & 7;
         double s = 0.0, s2 = 0.0;
         if (g < G) {
+#pragma unroll 8
             for (int k = sub; k < nsplit; k += 8) {
                 const float2 o = *reinterpret_cast<const float2*>(ws + (((int64_t)b * nsplit + k) * G + g) * 2);
                 s += o.x; s2 += o.y;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restri
         const int g = g0 + (int)threadIdx.x / 8, sub = threadIdx.x & 7;
         double s = 0.0, s2 = 0.0;
         if (g < G) {
+#pragma unroll 8  // the partial sums are independent loads: issue them together (same order of additions)
             for (int k = sub; k < items; k += 8) {
                 const int r = k / bpg, kb = g * bpg + (k - r * bpg);
                 const int64_t row = (int64_t)b * rb + r;
@@ -348,6 +350,91 @@ __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict_
             else o[k] = __float_as_uint(v[k % EP]);
         }
         *reinterpret_cast<vec_t*>(Yg + (int64_t)px * C + j * EP) = o;
+        px += dq; j += dr;
+        if (j >= vpr) { j -= vpr; ++px; }
+    }
+}
+
+// Register-resident form of gn_fused_kernel for slabs of at most 256 * MAXIT accesses (the SD-1.5 GroupNorms of the 16x16
+// level): ONE round trip to memory -- all of a thread's accesses are issued together and stay in registers through the two
+// reductions and the normalisation -- instead of three dependent passes of one load at a time (round 2: 9-10 us per launch for
+// 20-40 KB, pure latency).  Same items per thread in the same order, same reductions: bit-identical to gn_fused_kernel.
+template <typename T, int VB, int MAXIT>
+__global__ __launch_bounds__(kThreads) void gn_fused_reg_kernel(const T* __restrict__ X, T* __restrict__ Y, int HW, int C, int G,
+                                                                float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int silu) {
+    constexpr int EP = VB / (int)sizeof(T);
+    constexpr int NW = VB / 4;
+    typedef unsigned vec_t __attribute__((ext_vector_type(NW)));
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, vpr = cpg / EP;
+    const int total = HW * vpr;
+    const T* Xg = X + ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    T* Yg = Y + ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    const int dq = kThreads / vpr, dr = kThreads - dq * vpr;
+    const int px0 = (int)threadIdx.x / vpr, j0 = (int)threadIdx.x - px0 * vpr;
+    auto unpack = [](const vec_t& w, float (&v)[EP]) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            if constexpr (sizeof(T) == 2) Half<T>::unpack2(w[k], v[(2 * k) % EP], v[(2 * k + 1) % EP]);
+            else v[k] = __uint_as_float(w[k]);
+        }
+    };
+    vec_t raw[MAXIT];
+    {
+        int px = px0, j = j0;
+#pragma unroll
+        for (int k = 0; k < MAXIT; ++k) {
+            if ((int)threadIdx.x + k * kThreads < total) raw[k] = *reinterpret_cast<const vec_t*>(Xg + (int64_t)px * C + j * EP);
+            px += dq; j += dr;
+            if (j >= vpr) { j -= vpr; ++px; }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        if ((int)threadIdx.x + k * kThreads < total) {
+            float v[EP];
+            unpack(raw[k], v);
+#pragma unroll
+            for (int e = 0; e < EP; ++e) s += v[e];
+        }
+    }
+    const float n = (float)HW * (float)cpg;
+    const float mean = block_sum_256(s, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        if ((int)threadIdx.x + k * kThreads < total) {
+            float v[EP];
+            unpack(raw[k], v);
+#pragma unroll
+            for (int e = 0; e < EP; ++e) { const float a = v[e] - mean; q += a * a; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum_256(q, red) / n + eps);
+    int px = px0, j = j0;
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        if ((int)threadIdx.x + k * kThreads < total) {
+            float v[EP];
+            unpack(raw[k], v);
+            const int c0 = g * cpg + j * EP;
+#pragma unroll
+            for (int e = 0; e < EP; ++e) {
+                float a = (v[e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+                if (silu) a = silu_f(a);
+                v[e] = a;
+            }
+            vec_t o;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if constexpr (sizeof(T) == 2) o[w] = Half<T>::pack2(v[(2 * w) % EP], v[(2 * w + 1) % EP]);
+                else o[w] = __float_as_uint(v[w % EP]);
+            }
+            *reinterpret_cast<vec_t*>(Yg + (int64_t)px * C + j * EP) = o;
+        }
         px += dq; j += dr;
         if (j >= vpr) { j -= vpr; ++px; }
     }
@@ -652,7 +739,19 @@ int gmd_groupnorm_fused(const void* X, void* Y, int dtype, int B, int64_t HW, in
         return (cpg * esz) % vb == 0 && (C * esz) % vb == 0 && (reinterpret_cast<uintptr_t>(X) % vb) == 0 && (reinterpret_cast<uintptr_t>(Y) % vb) == 0;
     };
     const int vb = ok(16) ? 16 : ok(8) ? 8 : 4;
-#define GMD_GN_FUSED(T, VB) gn_fused_kernel<T, VB><<<grid, kThreads, 0, s>>>((const T*)X, (T*)Y, (int)HW, C, G, eps, gamma, beta, silu)
+    // slabs of 5..12 accesses per thread (the 16x16-level GroupNorms: 20-40 KB) stay in registers: one memory round trip instead
+    // of three dependent passes (tools/bench_gn.py: 11.0 -> 9.5 us at C = 1280, 21.2 -> 17.4 us at C = 2560).  Below that (8x8
+    // level, <= 4 accesses) the three short passes are as fast; the apply loops of the two-launch kernels did NOT gain from the
+    // same treatment (four loads in flight per thread, twice the workgroups: 24.8 us either way at 64x64) and were left alone.
+    const int64_t accesses = HW * (int64_t)(cpg * esz / vb);
+    const bool in_regs = vb >= 8 && accesses > (int64_t)kThreads * 4 && accesses <= (int64_t)kThreads * 12;
+#define GMD_GN_FUSED(T, VB)                                                                                                                 \
+    do {                                                                                                                                    \
+        if (in_regs && VB >= 8)                                                                                                             \
+            gn_fused_reg_kernel<T, (VB >= 8 ? VB : 8), 12><<<grid, kThreads, 0, s>>>((const T*)X, (T*)Y, (int)HW, C, G, eps, gamma, beta, silu); \
+        else                                                                                                                                \
+            gn_fused_kernel<T, VB><<<grid, kThreads, 0, s>>>((const T*)X, (T*)Y, (int)HW, C, G, eps, gamma, beta, silu);                   \
+    } while (0)
     gmd_for_dtype(dtype, [&](auto tag) {
         using T = decltype(tag);
         if (vb == 16) GMD_GN_FUSED(T, 16); else if (vb == 8) GMD_GN_FUSED(T, 8); else GMD_GN_FUSED(T, 4);
