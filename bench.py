@@ -273,9 +273,26 @@ def main():
     timer = None
     path_diff = None
     if not a.no_kernel_timing and rank == 0:
+        pipe.overlap_streams = False  # one stream: an event pair then brackets exactly one kernel running alone
+        # An event pair brackets a kernel only while the GPU has a backlog: when the GPU waits for the host (~33 k eager launches +
+        # 66 k event records per step, host time ~ GPU time), elapsed(e0, e1) also holds the wait for the next launch, and the
+        # short, numerous gemm_nt launches read 30 % too long on a box with a slow host (round 3: 36.8 vs 28.3 us average).  So
+        # the host gets a head start: a dry instrumented step measures the host's enqueue time, then the stream is blocked by a
+        # spinning kernel for that long (capped) while the host enqueues the measured step behind it.
+        profiling.set_timer(profiling.KernelTimer())
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        step()
+        host_enqueue_s = time.perf_counter() - t_h
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(20_000_000); e1.record()
+        torch.cuda.synchronize()
+        ticks_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+        host_lead_ms = min(host_enqueue_s * 1e3, 4000.0)
         timer = profiling.KernelTimer()
         profiling.set_timer(timer)  # an active timer makes the pipeline take the eager (non-graph) path
-        pipe.overlap_streams = False  # one stream: an event pair then brackets exactly one kernel running alone
+        torch.cuda._sleep(int(host_lead_ms * ticks_per_ms))
         out_eager, _, _ = step()
         torch.cuda.synchronize()
         profiling.set_timer(None)
@@ -328,9 +345,11 @@ def main():
                     step(f_pipe, f_vae)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
+                tol_each = []
                 for _ in range(a.tolerance_steps):
                     step(f_pipe, f_vae)
-                torch.cuda.synchronize()
+                    torch.cuda.synchronize()
+                    tol_each.append(round((time.perf_counter() - t1) * 1e3 - sum(tol_each), 1))
                 t_tol = time.perf_counter() - t1
                 # the split path against the exact float32 FMA kernels, same short run
                 hip_ops.set_f32_mode("exact")
@@ -345,7 +364,7 @@ def main():
                 tol_path = {
                     "dtype": "f32 (float32 tensors; every contraction as three float16 MFMA passes, f16 hi + f16 lo operands, fp32 accumulate)",
                     "images_per_s": round(B * a.tolerance_steps / t_tol, 4), "ms_per_step": round(t_tol / a.tolerance_steps * 1e3, 1),
-                    "steps": a.tolerance_steps, "workload": "same as config.workload (full batch, all inference steps, 2 float32 VAE decodes + tail)",
+                    "steps": a.tolerance_steps, "ms_each": tol_each, "workload": "same as config.workload (full batch, all inference steps, 2 float32 VAE decodes + tail)",
                     "latent_rms_vs_f32": {"sdr": float("%.3g" % rms(s_f, sdr_e)), "gm": float("%.3g" % rms(g_f, gm_e)),
                                           "sdr_rel": float("%.3g" % (rms(s_f, sdr_e) / lat_rms)), "reference": "exact float32 FMA kernels (GMD_F32_MODE=exact)",
                                           "pndm_steps": a.drift_steps, "prompts": 1},
@@ -398,7 +417,9 @@ def main():
                     ("flops_per_launch_avg" if mf else "bytes_per_launch_avg"): round((dom["flops"] if mf else dom["bytes"]) / dom["launches"]),
                     "measured": "HIP events around every launch of this kind in one extra eager, single-stream step after the timed "
                                 "region (the timed region replays HIP graphs on two streams, which events cannot enter); chosen as the "
-                                "kind with the largest measured time over ALL instrumented kinds",
+                                "kind with the largest measured time over ALL instrumented kinds; the stream is held by a spinning "
+                                "kernel for host_lead_ms while the host enqueues the step, so that no event pair includes a wait for the host",
+                    "host_enqueue_ms": round(host_enqueue_s * 1e3, 1), "host_lead_ms": round(host_lead_ms, 1),
                     "share_of_instrumented_kernel_time": round(dom["ms"] / all_ms, 3)}
         is_metric = a.scheduler == "pndm" and a.inference_steps == 50 and a.res == 512 and a.dtype == "bf16" and a.unet == "sd15"
         res = {

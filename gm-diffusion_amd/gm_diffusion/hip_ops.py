@@ -547,6 +547,24 @@ def concat_channels(a, b):
     return out
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """The second HIP stream of ``device`` (the GM UNet's, stable_diffusion_dual_unet.py).  ONE per device and process, shared by
+    every pipeline object: HIP multiplexes its streams onto a few hardware queues in the order they are first used, and a stream
+    drawn from torch's pool after a number of others (graph captures take several) can land on the queue the main stream uses --
+    the two UNets then run one after the other.  Measured in bench.py: a second pipeline with its own late stream 2036 ms per batch,
+    with this shared one 1817 ms (float32 path).  Default priority and HIP's default queue count on purpose: a high-priority GM
+    stream costs 1393 instead of 851 ms per batch, GPU_MAX_HW_QUEUES=8 1158 ms, =2 852 ms (tools/ab_queues.sh, bfloat16)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def dup_batch(t):
     """[B, ...] -> [2B, ...] with both halves equal to ``t`` (one read, two writes; the CFG duplication of a shared-prefix tensor)."""
     _dev(t)

@@ -50,6 +50,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 
 import torch
 
+from .. import hip_ops as ops
 from .stable_diffusion_gm import _GMPipelineBase, rescale_noise_cfg, retrieve_timesteps
 
 __all__ = ["StableDiffusionDualUNetPipeline", "rescale_noise_cfg", "retrieve_timesteps"]
@@ -65,7 +66,6 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                  image_encoder=None, requires_safety_checker: bool = True):
         self._init_common(vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor, image_encoder,
                           requires_safety_checker, gm_unet=gm_unet)
-        self._gm_streams = {}
 
     @staticmethod
     def _batched_added_cond(added_cond, do_cfg, device):
@@ -83,10 +83,7 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                     time_ids=torch.cat([neg_ids, pos["time_ids"]])), pos
 
     def _gm_stream(self, device):
-        s = self._gm_streams.get(device)
-        if s is None:
-            s = self._gm_streams[device] = torch.cuda.Stream(device=device)
-        return s
+        return ops.side_stream(device)  # one per device for the whole process, not per pipeline object (see there)
 
     @torch.no_grad()
     def __call__(

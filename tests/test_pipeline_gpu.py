@@ -156,6 +156,30 @@ def test_graph_replay_equals_eager_and_streams():
     assert torch.equal(d[0], e[0]) and torch.equal(d[1], e[1]) and not torch.equal(d[0], a[0])
 
 
+def test_pipelines_share_one_side_stream_per_device():
+    """Two pipeline objects in one process (bench.py: the bfloat16 headline and the float32 tolerance path) run their GM UNets on
+    the SAME second stream -- a stream drawn late from torch's pool lost the overlap (hip_ops.side_stream: 2036 vs 1817 ms) -- and
+    two pipelines alternating on it stay bit-identical to their single-stream runs."""
+    from gm_diffusion import hip_ops as ops
+    p1, p2 = _dual_pipe(torch.bfloat16), _dual_pipe(torch.float16)
+    s1, s2 = p1._gm_stream(DEV), p2._gm_stream(torch.device(DEV))
+    assert s1 is s2 and s1 is ops.side_stream("cuda") and s1 != torch.cuda.current_stream()
+    g = torch.Generator().manual_seed(6)
+    pe, ne = torch.randn(2, 77, 64, generator=g).to(DEV), torch.randn(2, 77, 64, generator=g).to(DEV)
+    lat = torch.randn(2, 4, 16, 16, generator=g).to(DEV)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=128, width=128, num_inference_steps=4, output_type="latent")
+    outs = {}
+    for name, p in (("a", p1), ("b", p2)):
+        p.set_progress_bar_config(disable=True)
+        p.overlap_streams = False
+        outs[name] = p(**kw)
+        p.overlap_streams = True
+    for _ in range(2):  # alternate on the shared stream
+        for name, p in (("a", p1), ("b", p2)):
+            o = p(**kw)
+            assert torch.equal(o[0], outs[name][0]) and torch.equal(o[1], outs[name][1])
+
+
 def test_dual_pipeline_dpm_solver_on_device_matches_oracle():
     """the DPM-Solver++ swap the reference makes (formal_improved.py:195) runs the HIP models through
     the generic scheduler protocol; fp32 latents must match the oracle loop within the north-star tolerance."""

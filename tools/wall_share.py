@@ -21,7 +21,7 @@ from gm_diffusion.components import unet_2d_condition as U
 from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--by", default="level", choices=["level", "kind", "part"])
+ap.add_argument("--by", default="level", choices=["level", "kind", "part", "linear"])
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--batch", type=int, default=4)
@@ -69,7 +69,18 @@ def conv3x3(x, w, Bn, H, W, **kw):
 def gemm_nt(a_, w, **kw):
     if a_.dim() == 2 and w.dim() == 2 and a_.shape[0] >= 64:
         tok = _tokens_of_rows(a_.shape[0], None)
-        if tok and SKIP("linear", tok, TAG[0]):
+        n_, k_ = w.shape[0], a_.shape[1]
+        if kw.get("act") == ops.ACT_GEGLU:
+            tag = "ff1"
+        elif k_ == 4 * n_:
+            tag = "ff2"
+        elif n_ == 2 * k_:
+            tag = "qk"
+        elif n_ == k_:
+            tag = "cc_res" if kw.get("residual") is not None else "cc"
+        else:
+            tag = "other"
+        if tok and SKIP("linear", tok, tag):
             n = w.shape[0] // 2 if kw.get("act") == ops.ACT_GEGLU else w.shape[0]
             out = kw.get("out")
             return out if out is not None else torch.empty((a_.shape[0], n), dtype=kw.get("out_dtype") or a_.dtype, device=a_.device)
@@ -144,6 +155,19 @@ elif a.by == "kind":
     for tok, name in LEVEL_TOKENS.items():
         for kind in ("conv", "linear", "attention", "norm"):
             exps.append((f"{name}: {kind}", lambda k, t, tag, tok=tok, kind=kind: t == tok and k == kind))
+elif a.by == "linear":
+    exps = [("C->C projections with residual (o1, o2, proj_out)", lambda k, t, tag: k == "linear" and tag == "cc_res"),
+            ("C->C projections without (q2, proj_in)", lambda k, t, tag: k == "linear" and tag == "cc"),
+            ("q|k projection (N = 2C)", lambda k, t, tag: k == "linear" and tag == "qk"),
+            ("V^T projection", lambda k, t, tag: k == "linear" and tag == "vt"),
+            ("feed-forward (ff1 GEGLU, ff2, fused)", lambda k, t, tag: k == "linear" and tag in ("ff1", "ff2", "ff")),
+            ("all LayerNorms", lambda k, t, tag: k == "norm" and tag == "ln"),
+            ("64x64: C->C projections, both kinds", lambda k, t, tag: k == "linear" and tag in ("cc", "cc_res") and t == 4096),
+            ("32x32: C->C projections, both kinds", lambda k, t, tag: k == "linear" and tag in ("cc", "cc_res") and t == 1024),
+            ("16x16: C->C projections, both kinds", lambda k, t, tag: k == "linear" and tag in ("cc", "cc_res") and t == 256),
+            ("64x64: everything row-local after self-attention (o1..proj_out, LN2/3, cross-attention, FF)",
+             lambda k, t, tag: t == 4096 and ((k == "linear" and tag in ("cc", "cc_res", "ff1", "ff2", "ff")) or (k == "attention" and tag == "cross"))),
+            ]
 else:
     exps = [("self-attention kernels (all levels)", lambda k, t, tag: k == "attention" and tag == "self"),
             ("cross-attention kernels (all levels)", lambda k, t, tag: k == "attention" and tag == "cross"),
