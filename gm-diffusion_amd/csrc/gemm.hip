@@ -22,6 +22,7 @@
 // gemm_split.hip: float32 on the matrix cores as three float16 products (GMD_F32S / GMD_F32SW)
 int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
 int gmd_launch_split_conv(const void* params, int w_presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
+int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes);
 
 namespace {
 
@@ -1142,7 +1143,7 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
         else if (pl.bm == 64 && pl.bn == 64) e = launch_bf16<HT, CONV, 64, 64, 0>(p, gz, s);
         else { gmd_set_error("%s: tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
     }
-    if (e == hipSuccess && pl.ksplit > 1) {
+    if (e == hipSuccess && pl.ksplit > 1 && !p.defer_reduce) {
         const int64_t total = (int64_t)p.M * ((p.N + 7) / 8);
         int64_t g = (total + 255) / 256;
         if (g > 4096) g = 4096;
@@ -1243,9 +1244,37 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
 }
 
-int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
-                int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
-                float alpha, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+}  // extern "C"
+
+namespace {
+
+// GroupNorm (+SiLU) of the convolution's output, fused behind a split-K plan (gmd_conv3x3_groupnorm)
+struct GnTail {
+    void* Ynorm;
+    int G;
+    float eps;
+    const float* gamma;
+    const float* beta;
+    int silu;
+};
+
+void conv_out_shape(int Hin, int Win, int stride, int upsample, int pad_mode, int& Hout, int& Wout, int& pad_lo) {
+    if (upsample) { Hout = 2 * Hin; Wout = 2 * Win; pad_lo = 1; }
+    else if (pad_mode == 1) { Hout = (Hin + 1 - 3) / 2 + 1; Wout = (Win + 1 - 3) / 2 + 1; pad_lo = 0; }
+    else { Hout = (Hin + 2 - 3) / stride + 1; Wout = (Win + 2 - 3) / stride + 1; pad_lo = 1; }
+}
+
+// split-K factor the conv launch will use (1 = unsplit); the same planners the launch itself calls
+int conv_plan_ksplit(int dtype, int64_t M, int Cin, int Cout, int64_t ws_bytes) {
+    if (dtype == GMD_F32S || dtype == GMD_F32SW) return gmd_split_plan_ksplit((int)M, Cout, 9 * Cin, ws_bytes);
+    if (gmd_is_half(dtype)) return make_plan((int)M, Cout, 9 * Cin, 1, ws_bytes, false).ksplit;
+    return 1;
+}
+
+int conv3x3_impl(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
+                 int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
+                 float alpha, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream,
+                 const GnTail* gn) {
     const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32 || split, "gmd_conv3x3: bad dtype %d", dtype);
     const bool is16 = gmd_is_half(dtype);
@@ -1257,14 +1286,12 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     GMD_REQUIRE(pad_mode == 0 || (pad_mode == 1 && stride == 2 && !upsample), "gmd_conv3x3: pad_mode 1 requires stride 2");
     const int kmul = is16 ? 64 : split ? 32 : 16;
     GMD_REQUIRE(Cin % kmul == 0, "gmd_conv3x3: Cin=%d must be a multiple of %d (pad the channels)", Cin, kmul);
-    GMD_REQUIRE(X && Wt && Y && gmd_aligned16(X) && gmd_aligned16(Wt) && gmd_aligned16(Y), "gmd_conv3x3: null or unaligned pointer");
+    GMD_REQUIRE(X && Wt && (Y || gn) && gmd_aligned16(X) && gmd_aligned16(Wt) && gmd_aligned16(Y), "gmd_conv3x3: null or unaligned pointer");
     GMD_REQUIRE(bias == nullptr || gmd_aligned16(bias), "gmd_conv3x3: bias must be 16-byte aligned (it is read with float4 loads)");
     GMD_REQUIRE(residual == nullptr || gmd_aligned16(residual), "gmd_conv3x3: unaligned residual");
     GMD_REQUIRE(residual == nullptr || out_dtype == dtype || !is16, "gmd_conv3x3: residual needs out_dtype == dtype");
     int Hout, Wout, pad_lo;
-    if (upsample) { Hout = 2 * Hin; Wout = 2 * Win; pad_lo = 1; }
-    else if (pad_mode == 1) { Hout = (Hin + 1 - 3) / 2 + 1; Wout = (Win + 1 - 3) / 2 + 1; pad_lo = 0; }
-    else { Hout = (Hin + 2 - 3) / stride + 1; Wout = (Win + 2 - 3) / stride + 1; pad_lo = 1; }
+    conv_out_shape(Hin, Win, stride, upsample, pad_mode, Hout, Wout, pad_lo);
     const int64_t M = (int64_t)B * Hout * Wout;
     GMD_REQUIRE(M < (1LL << 31), "gmd_conv3x3: too many output pixels");
     GemmParams p{};
@@ -1282,11 +1309,59 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.upsample = upsample; p.pad_lo = pad_lo;
     p.cblk = conv_channel_block(B, Hin, Win, Cin, Cout, dtype);
     p.colstats = colstats; p.cs_bucket = colstats_bucket;
-    if (split) {
-        GMD_REQUIRE(!colstats, "gmd_conv3x3: column statistics are implemented for the 16-bit types only");
-        return gmd_launch_split_conv(&p, dtype == GMD_F32SW, B, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
+    int ks = 1;
+    if (gn) {  // the split-K slabs stay in the workspace; the GroupNorm kernel sums them (no reduce launch, no raw tensor unless Y)
+        const int act_dtype = split ? GMD_F32 : dtype;
+        ks = workspace ? conv_plan_ksplit(dtype, M, Cin, Cout, workspace_bytes) : 1;
+        if (ks <= 1 || colstats || out_dtype != act_dtype || !gmd_gn_from_slabs_ok(act_dtype, B, (int64_t)Hout * Wout, Cout, gn->G)) {
+            gmd_set_error("gmd_conv3x3_groupnorm: this launch does not fuse (split-K factor %d; ask gmd_conv3x3_gn_fusable first)", ks);
+            return GMD_ERR_UNSUPPORTED;
+        }
+        p.defer_reduce = 1;
     }
-    return launch<true>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
+    const int rc = split ? gmd_launch_split_conv(&p, dtype == GMD_F32SW, B, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3")
+                         : launch<true>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
+    if (rc != GMD_OK || !gn) return rc;
+    return gmd_launch_gn_from_slabs((const float*)workspace, ks, alpha, bias, rowbias, p.ldrb, residual, Y, gn->Ynorm, split ? GMD_F32 : dtype, B,
+                                    (int64_t)Hout * Wout, Cout, gn->G, gn->eps, gn->gamma, gn->beta, gn->silu, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype, int B, int Hin, int Win, int Cin, int Cout,
+                int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
+                float alpha, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+    return conv3x3_impl(X, Wt, Y, dtype, out_dtype, B, Hin, Win, Cin, Cout, stride, upsample, pad_mode, bias, rowbias, ldrb, residual, alpha,
+                        colstats, colstats_bucket, workspace, workspace_bytes, stream, nullptr);
+}
+
+int gmd_conv3x3_gn_fusable(int dtype, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode, int groups,
+                           int64_t workspace_bytes) {
+    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;
+    if (!(gmd_is_half(dtype) || split) || B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0) return 0;
+    if (!(stride == 1 || stride == 2) || (upsample && stride != 1) || !(pad_mode == 0 || (pad_mode == 1 && stride == 2 && !upsample))) return 0;
+    int Hout, Wout, pad_lo;
+    conv_out_shape(Hin, Win, stride, upsample, pad_mode, Hout, Wout, pad_lo);
+    const int64_t M = (int64_t)B * Hout * Wout;
+    if (M >= (1LL << 31) || Cin % (split ? 32 : 64)) return 0;
+    // one workgroup per (sample, group) walks all slabs of its slice: below one workgroup per CU the separate, fully parallel
+    // reduction wins (tools/bench_conv_gn.py: batch 4 x 32 groups loses 3-5 us per site, batch 8 wins 2-5 us)
+    if ((int64_t)B * groups < 256) return 0;
+    return conv_plan_ksplit(dtype, M, Cin, Cout, workspace_bytes) > 1 &&
+           gmd_gn_from_slabs_ok(split ? GMD_F32 : dtype, B, (int64_t)Hout * Wout, Cout, groups) ? 1 : 0;
+}
+
+int gmd_conv3x3_groupnorm(const void* X, const void* Wt, void* Yraw, void* Ynorm, int dtype, int B, int Hin, int Win, int Cin, int Cout,
+                          int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb,
+                          const void* residual, float alpha, int groups, float eps, const float* gamma, const float* beta, int silu,
+                          void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+    GMD_REQUIRE(Ynorm && gamma && beta && groups > 0 && gmd_aligned16(Ynorm), "gmd_conv3x3_groupnorm: null or unaligned GroupNorm argument");
+    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;
+    const GnTail gn{Ynorm, groups, eps, gamma, beta, silu};
+    return conv3x3_impl(X, Wt, Yraw, dtype, split ? GMD_F32 : dtype, B, Hin, Win, Cin, Cout, stride, upsample, pad_mode, bias, rowbias, ldrb,
+                        residual, alpha, nullptr, 0, workspace, workspace_bytes, stream, &gn);
 }
 
 }  // extern "C"

@@ -34,6 +34,9 @@ struct GemmParams {
     // 64-row block and each bucket of `cs_bucket` adjacent columns -> colstats[M/64][N/cs_bucket][2] (ring kernel, row epilogue)
     float* colstats;
     int cs_bucket;
+    // split-K only: leave the partial slabs in `ws` and do NOT launch the reduction (the consumer sums them:
+    // gmd_conv3x3_groupnorm -> gn_slab_kernel of norm.hip)
+    int defer_reduce;
 };
 
 // Row-invariant part of the A address of one staging slot.

@@ -608,7 +608,7 @@ int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStr
     if (pl.bm == 128 && pl.bn == 160) e = launch_split<CONV, WSPLIT, 2, 2, 4, 5, 2>(p, gz, s);
     else if (pl.bm == 128) e = launch_split<CONV, WSPLIT, 2, 2, 4, 4, 2>(p, gz, s);
     else e = launch_split<CONV, WSPLIT, 2, 2, 2, 2, 2>(p, gz, s);
-    if (e == hipSuccess && pl.ksplit > 1) {
+    if (e == hipSuccess && pl.ksplit > 1 && !p.defer_reduce) {
         const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
         int64_t g = (total + 255) / 256;
         if (g > 4096) g = 4096;
@@ -637,6 +637,9 @@ int split_channel_block(int B, int Hin, int Win, int Cin, int Cout) {
 }
 
 }  // namespace
+
+// split-K factor launch_split_any will choose (no GEGLU): gmd_conv3x3_groupnorm / gmd_conv3x3_gn_fusable of gemm.hip
+int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes) { return make_split_plan(M, N, K, 1, ws_bytes).ksplit; }
 
 // called by gmd_gemm_nt / gmd_conv3x3 (gemm.hip) for the two split dtype codes; the parameter block is validated there
 int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {

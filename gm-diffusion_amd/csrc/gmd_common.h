@@ -146,6 +146,13 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[4]) {
 }
 
 // host side: dtype codes -> element types
+// GroupNorm straight from split-K partial slabs (norm.hip, used by gmd_conv3x3_groupnorm in gemm.hip).  `dtype` is the ACTIVATION
+// type (GMD_BF16 / GMD_F16 / GMD_F32).  _ok: the (sample, group) slice fits the register-resident kernel with 16-byte accesses.
+bool gmd_gn_from_slabs_ok(int dtype, int B, int64_t HW, int C, int G);
+int gmd_launch_gn_from_slabs(const float* ws, int ksplit, float alpha, const float* bias, const float* rowbias, int64_t ldrb,
+                             const void* residual, void* Yraw, void* Ynorm, int dtype, int B, int64_t HW, int C, int G, float eps,
+                             const float* gamma, const float* beta, int silu, hipStream_t stream);
+
 static inline bool gmd_is_half(int dtype) { return dtype == GMD_BF16 || dtype == GMD_F16; }
 static inline bool gmd_known_dtype(int dtype) { return dtype == GMD_F32 || gmd_is_half(dtype); }
 // run f(T{}) with T = float / bf16_t / f16_t (the caller has validated the code)

@@ -359,38 +359,25 @@ __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict_
 // level): ONE round trip to memory -- all of a thread's accesses are issued together and stay in registers through the two
 // reductions and the normalisation -- instead of three dependent passes of one load at a time (round 2: 9-10 us per launch for
 // 20-40 KB, pure latency).  Same items per thread in the same order, same reductions: bit-identical to gn_fused_kernel.
+// gn_reg_finish is the part after the loads: statistics, normalisation, store (shared with gn_slab_kernel below).
 template <typename T, int VB, int MAXIT>
-__global__ __launch_bounds__(kThreads) void gn_fused_reg_kernel(const T* __restrict__ X, T* __restrict__ Y, int HW, int C, int G,
-                                                                float eps, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, int silu) {
+__device__ __forceinline__ void gn_reg_finish(const unsigned (&raw)[MAXIT][VB / 4], T* __restrict__ Yg, int HW, int C, int g, int cpg,
+                                              float eps, const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                              float* red) {
     constexpr int EP = VB / (int)sizeof(T);
     constexpr int NW = VB / 4;
     typedef unsigned vec_t __attribute__((ext_vector_type(NW)));
-    __shared__ float red[4];
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int cpg = C / G, vpr = cpg / EP;
+    const int vpr = cpg / EP;
     const int total = HW * vpr;
-    const T* Xg = X + ((int64_t)b * HW) * C + (int64_t)g * cpg;
-    T* Yg = Y + ((int64_t)b * HW) * C + (int64_t)g * cpg;
     const int dq = kThreads / vpr, dr = kThreads - dq * vpr;
     const int px0 = (int)threadIdx.x / vpr, j0 = (int)threadIdx.x - px0 * vpr;
-    auto unpack = [](const vec_t& w, float (&v)[EP]) {
+    auto unpack = [](const unsigned (&w)[NW], float (&v)[EP]) {
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             if constexpr (sizeof(T) == 2) Half<T>::unpack2(w[k], v[(2 * k) % EP], v[(2 * k + 1) % EP]);
             else v[k] = __uint_as_float(w[k]);
         }
     };
-    vec_t raw[MAXIT];
-    {
-        int px = px0, j = j0;
-#pragma unroll
-        for (int k = 0; k < MAXIT; ++k) {
-            if ((int)threadIdx.x + k * kThreads < total) raw[k] = *reinterpret_cast<const vec_t*>(Xg + (int64_t)px * C + j * EP);
-            px += dq; j += dr;
-            if (j >= vpr) { j -= vpr; ++px; }
-        }
-    }
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
@@ -438,6 +425,163 @@ __global__ __launch_bounds__(kThreads) void gn_fused_reg_kernel(const T* __restr
         px += dq; j += dr;
         if (j >= vpr) { j -= vpr; ++px; }
     }
+}
+
+template <typename T, int VB, int MAXIT>
+__global__ __launch_bounds__(kThreads) void gn_fused_reg_kernel(const T* __restrict__ X, T* __restrict__ Y, int HW, int C, int G,
+                                                                float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int silu) {
+    constexpr int EP = VB / (int)sizeof(T);
+    constexpr int NW = VB / 4;
+    typedef unsigned vec_t __attribute__((ext_vector_type(NW)));
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, vpr = cpg / EP;
+    const int total = HW * vpr;
+    const T* Xg = X + ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    T* Yg = Y + ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    const int dq = kThreads / vpr, dr = kThreads - dq * vpr;
+    const int px0 = (int)threadIdx.x / vpr, j0 = (int)threadIdx.x - px0 * vpr;
+    unsigned raw[MAXIT][NW];
+    {
+        int px = px0, j = j0;
+#pragma unroll
+        for (int k = 0; k < MAXIT; ++k) {
+            if ((int)threadIdx.x + k * kThreads < total) {
+                const vec_t w = *reinterpret_cast<const vec_t*>(Xg + (int64_t)px * C + j * EP);
+#pragma unroll
+                for (int e = 0; e < NW; ++e) raw[k][e] = w[e];
+            }
+            px += dq; j += dr;
+            if (j >= vpr) { j -= vpr; ++px; }
+        }
+    }
+    gn_reg_finish<T, VB, MAXIT>(raw, Yg, HW, C, g, cpg, eps, gamma, beta, silu, red);
+}
+
+// GroupNorm (+SiLU) straight from the float32 partial slabs of a split-K convolution / GEMM (gmd_conv3x3_groupnorm): the
+// workgroup of one (sample, group) sums its columns of the `ksplit` slabs in slab order, applies the producer's epilogue (alpha,
+// bias, row bias, residual -- the association of splitk_reduce_kernel for the 16-bit types and of splitk_reduce_f32_kernel for
+// float32), rounds to the activation type exactly as the stored tensor would be rounded, optionally stores that tensor, and
+// normalises from registers.  Replaces splitk_reduce + GroupNorm: the reduced tensor is neither written nor re-read (unless the
+// caller wants it), one launch less.  Items, order and reductions are those of gn_fused_kernel on the reduced tensor, so the
+// result is bit-identical to the two-launch path.  16-byte accesses of the OUTPUT type only (cpg * sizeof(T) % 16 == 0).
+struct SlabSource {
+    const float* ws;       // [ksplit][M][C] partial sums
+    int ksplit;
+    int64_t slab;          // M * C
+    float alpha;
+    const float* bias;     // [C] or null
+    const float* rowbias;  // [B][ldrb] or null
+    int64_t ldrb;
+    const void* residual;  // [M][C] of T or null
+};
+
+template <typename T, int MAXIT>
+__global__ __launch_bounds__(kThreads) void gn_slab_kernel(const SlabSource sp, T* __restrict__ Yraw, T* __restrict__ Y, int HW, int C,
+                                                           int G, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int silu) {
+    constexpr int EP = 16 / (int)sizeof(T);  // elements per item: 8 (16-bit) or 4 (float32)
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, vpr = cpg / EP;
+    const int total = HW * vpr;
+    const int64_t base = ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    const int dq = kThreads / vpr, dr = kThreads - dq * vpr;
+    const int px0 = (int)threadIdx.x / vpr, j0 = (int)threadIdx.x - px0 * vpr;
+    int off[MAXIT], ch[MAXIT];  // element offset inside the (sample, group) slice / first channel of the item
+    {
+        int px = px0, j = j0;
+#pragma unroll
+        for (int k = 0; k < MAXIT; ++k) {
+            off[k] = px * C + j * EP;
+            ch[k] = g * cpg + j * EP;
+            px += dq; j += dr;
+            if (j >= vpr) { j -= vpr; ++px; }
+        }
+    }
+    float acc[MAXIT][EP];
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) acc[k][e] = 0.f;
+    // U slabs per round: all of a thread's loads of U slabs are in flight together (one workgroup per CU at most -- the grid is
+    // G x B -- so registers are free and the chain of dependent round trips is what costs), added in slab order
+    constexpr int U = MAXIT <= 2 ? 8 : MAXIT <= 6 ? 4 : 2;
+    const float* src = sp.ws + base;
+    for (int s = 0; s < sp.ksplit; s += U, src += U * sp.slab) {
+        float4 t[U][MAXIT][EP / 4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s + u < sp.ksplit) {
+#pragma unroll
+                for (int k = 0; k < MAXIT; ++k)
+                    if ((int)threadIdx.x + k * kThreads < total) {
+#pragma unroll
+                        for (int h = 0; h < EP / 4; ++h) t[u][k][h] = *reinterpret_cast<const float4*>(src + u * sp.slab + off[k] + 4 * h);
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s + u < sp.ksplit) {
+#pragma unroll
+                for (int k = 0; k < MAXIT; ++k)
+                    if ((int)threadIdx.x + k * kThreads < total) {
+#pragma unroll
+                        for (int h = 0; h < EP / 4; ++h) {
+                            acc[k][4 * h] += t[u][k][h].x; acc[k][4 * h + 1] += t[u][k][h].y;
+                            acc[k][4 * h + 2] += t[u][k][h].z; acc[k][4 * h + 3] += t[u][k][h].w;
+                        }
+                    }
+            }
+        }
+    }
+    const float* rb = sp.rowbias ? sp.rowbias + (int64_t)b * sp.ldrb : nullptr;
+    unsigned raw[MAXIT][4];
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        if ((int)threadIdx.x + k * kThreads < total) {
+            float rv[EP];
+            if (sp.residual) {
+                typedef unsigned vec_t __attribute__((ext_vector_type(4)));
+                const vec_t w = *reinterpret_cast<const vec_t*>((const T*)sp.residual + base + off[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (sizeof(T) == 2) Half<T>::unpack2(w[e], rv[2 * e], rv[2 * e + 1]);
+                    else rv[e] = __uint_as_float(w[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EP; ++e) {
+                float x = acc[k][e] * sp.alpha;
+                if (sp.bias) x += sp.bias[ch[k] + e];
+                if constexpr (sizeof(T) == 2) {  // ((acc*alpha + bias) + rowbias) + residual: epilogue_store8 of gemm.hip
+                    if (rb) x += rb[ch[k] + e];
+                    if (sp.residual) x += rv[e];
+                } else {                         // (acc*alpha + bias) + (residual + rowbias): splitk_reduce_f32_kernel
+                    float add = 0.f;
+                    if (sp.residual) add += rv[e];
+                    if (rb) add += rb[ch[k] + e];
+                    x += add;
+                }
+                acc[k][e] = x;
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if constexpr (sizeof(T) == 2) raw[k][w] = Half<T>::pack2(acc[k][2 * w], acc[k][2 * w + 1]);
+                else raw[k][w] = __float_as_uint(acc[k][w]);
+            }
+            if (Yraw) {
+                typedef unsigned vec_t __attribute__((ext_vector_type(4)));
+                vec_t o;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] = raw[k][w];
+                *reinterpret_cast<vec_t*>(Yraw + base + off[k]) = o;
+            }
+        }
+    }
+    gn_reg_finish<T, 16, MAXIT>(raw, Y + base, HW, C, g, cpg, eps, gamma, beta, silu, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -603,6 +747,35 @@ inline int grid_for(int64_t n) {
 }
 
 }  // namespace
+
+bool gmd_gn_from_slabs_ok(int dtype, int B, int64_t HW, int C, int G) {
+    if (!gmd_known_dtype(dtype) || B <= 0 || B > 65535 || HW <= 0 || C <= 0 || G <= 0 || C % G) return false;
+    const int esz = gmd_is_half(dtype) ? 2 : 4, cpg = C / G;
+    if ((cpg * esz) % 16 || (C * esz) % 16 || HW * (int64_t)C >= (1LL << 31)) return false;
+    return HW * (int64_t)(cpg * esz / 16) <= (int64_t)kThreads * 12;
+}
+
+int gmd_launch_gn_from_slabs(const float* ws, int ksplit, float alpha, const float* bias, const float* rowbias, int64_t ldrb,
+                             const void* residual, void* Yraw, void* Ynorm, int dtype, int B, int64_t HW, int C, int G, float eps,
+                             const float* gamma, const float* beta, int silu, hipStream_t stream) {
+    GMD_REQUIRE(gmd_gn_from_slabs_ok(dtype, B, HW, C, G), "GroupNorm from split-K slabs: shape not supported (B=%d HW=%lld C=%d G=%d)", B,
+                (long long)HW, C, G);
+    GMD_REQUIRE(ws && ksplit >= 1 && Ynorm && gamma && beta && gmd_aligned16(ws) && gmd_aligned16(Ynorm) && (Yraw == nullptr || gmd_aligned16(Yraw)) &&
+                    (residual == nullptr || gmd_aligned16(residual)),
+                "GroupNorm from split-K slabs: null or unaligned pointer");
+    SlabSource sp{ws, ksplit, (int64_t)B * HW * C, alpha, bias, rowbias, ldrb > 0 ? ldrb : C, residual};
+    const int esz = gmd_is_half(dtype) ? 2 : 4;
+    const int64_t accesses = HW * (int64_t)((C / G) * esz / 16);
+    dim3 grid(G, B);
+    gmd_for_dtype(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        if (accesses <= (int64_t)kThreads * 2) gn_slab_kernel<T, 2><<<grid, kThreads, 0, stream>>>(sp, (T*)Yraw, (T*)Ynorm, (int)HW, C, G, eps, gamma, beta, silu);
+        else if (accesses <= (int64_t)kThreads * 6) gn_slab_kernel<T, 6><<<grid, kThreads, 0, stream>>>(sp, (T*)Yraw, (T*)Ynorm, (int)HW, C, G, eps, gamma, beta, silu);
+        else gn_slab_kernel<T, 12><<<grid, kThreads, 0, stream>>>(sp, (T*)Yraw, (T*)Ynorm, (int)HW, C, G, eps, gamma, beta, silu);
+    });
+    GMD_CHECK_LAUNCH("gmd_conv3x3_groupnorm (GroupNorm from slabs)");
+    return GMD_OK;
+}
 
 extern "C" {
 

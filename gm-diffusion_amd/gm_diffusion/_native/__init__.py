@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 GMD_F32, GMD_BF16, GMD_F16, GMD_F32S, GMD_F32SW = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -46,6 +46,8 @@ SIGNATURES = {
     "gmd_ff_geglu_fused_supported": [I, L, I],
     "gmd_ff_geglu_fused": [P, P, P, P, P, P, P, I, L, I, P],
     "gmd_conv3x3": [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, L, P, F, P, I, P, L, P],
+    "gmd_conv3x3_gn_fusable": [I, I, I, I, I, I, I, I, I, I, L],
+    "gmd_conv3x3_groupnorm": [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, L, P, F, I, F, P, P, I, P, L, P],
     "gmd_attention": [P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],
     "gmd_softmax_rows": [P, L, P, I, L, L, I, F, I, P],
     "gmd_groupnorm_nsplit": [L],

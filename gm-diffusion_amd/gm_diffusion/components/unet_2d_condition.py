@@ -494,8 +494,9 @@ class UNet2DConditionModel(_HipModule):
         G = self.config.norm_num_groups
         cs = self._wants_colstats(H, W)  # the GroupNorm that reads a conv output takes its statistics from the conv epilogue
         h = ops.groupnorm(x, B, G, r["n1"][0], r["n1"][1], eps, silu=True)
-        h, _, _ = ops.conv3x3(h, r["c1"][0], B, H, W, bias=r["c1"][1], rowbias=(temb, r["te_off"]), colstats=cs)
-        h = ops.groupnorm(h, B, G, r["n2"][0], r["n2"][1], eps, silu=True)
+        # conv1 -> + time embedding -> norm2 -> SiLU: one GroupNorm launch over the split-K slabs on the 16x16 / 8x8 levels
+        _, h = ops.conv3x3_groupnorm(h, r["c1"][0], B, H, W, G, r["n2"][0], r["n2"][1], eps, silu=True, bias=r["c1"][1],
+                                     rowbias=(temb, r["te_off"]), colstats=cs)
         if "sc" in r:
             cin = x.shape[-1]
             x = ops.gemm_nt(x.view(-1, cin), r["sc"][0], bias=r["sc"][1]).view(B, H * W, -1)

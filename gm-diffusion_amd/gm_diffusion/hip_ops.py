@@ -353,6 +353,45 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     return y, ho, wo
 
 
+USE_CONV_GN_FUSION = os.environ.get("GMD_CONV_GN", "1") != "0"  # (the switch: A/B measurements only)
+
+
+def conv3x3_groupnorm(x, w, B, H, W, groups, gamma, beta, eps, silu=True, bias=None, rowbias=None, residual=None, want_raw=False,
+                      colstats=False):
+    """GroupNorm(+SiLU) of conv3x3(x): returns (raw or None, normalised).  Where the convolution runs split-K and the group slices
+    are small (the 16x16 / 8x8 UNet levels) ONE GroupNorm launch sums the partial slabs, applies the convolution's epilogue and
+    normalises (gmd_conv3x3_groupnorm: no reduce launch, the raw tensor is written only if ``want_raw``); everywhere else this
+    is conv3x3 (+ producer statistics if ``colstats``) followed by groupnorm -- bit-identical either way."""
+    _dev(x, w, bias, residual, gamma, beta)
+    cin, cout = x.shape[-1], w.shape[0]
+    code = _contract_code(x, w, cin) if x.dtype == w.dtype and w.shape[1] == 9 * cin else -1
+    if not (USE_CONV_GN_FUSION and code >= 0 and
+            lib().gmd_conv3x3_gn_fusable(code, B, H, W, cin, cout, 1, 0, 0, groups, WORKSPACE_BYTES)):
+        y, _, _ = conv3x3(x, w, B, H, W, bias=bias, rowbias=rowbias, residual=residual, colstats=colstats)
+        return (y if want_raw else None), groupnorm(y, B, groups, gamma, beta, eps, silu=silu)
+    if x.numel() != B * H * W * cin:
+        raise HipExtensionError(f"conv3x3_groupnorm: shape mismatch x={tuple(x.shape)} B,H,W={B},{H},{W}")
+    if residual is not None and (residual.numel() != B * H * W * cout or residual.dtype != x.dtype):
+        raise HipExtensionError("conv3x3_groupnorm: residual shape/dtype mismatch")
+    if rowbias is not None and (rowbias[0] if isinstance(rowbias, tuple) else rowbias).shape[0] != B:
+        raise HipExtensionError("conv3x3_groupnorm: rowbias must have one row per sample")
+    rb_ptr, rb_ld = _rowbias(rowbias)
+    yn = torch.empty((B, H * W, cout), dtype=x.dtype, device=x.device)
+    yr = torch.empty_like(yn) if want_raw else None
+    ws = _workspace(x.device)
+    tm = profiling.active()
+    tm = tm if tm is not None and tm.wants("conv3x3") else None
+    t0 = tm.begin() if tm else None
+    check(lib().gmd_conv3x3_groupnorm(_ptr(x), _ptr(w), _ptr(yr), _ptr(yn), code, B, H, W, cin, cout, 1, 0, 0, _ptr(_f32(bias, "bias")),
+                                      rb_ptr, rb_ld, _ptr(residual), float(getattr(w, "_alpha", 1.0)), groups, float(eps),
+                                      _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), int(silu), _ptr(ws), WORKSPACE_BYTES, _stream()),
+          "gmd_conv3x3_groupnorm")
+    if tm:  # counted as the convolution it replaces (its FLOPs; the GroupNorm's bytes ride along)
+        tm.end("conv3x3", 2.0 * B * H * W * cout * 9 * cin, x.numel() * x.element_size() + w.numel() * w.element_size()
+               + yn.numel() * yn.element_size(), t0)
+    return yr, yn
+
+
 SPLIT_ATTENTION_HEAD_DIMS = (40, 64, 80, 160)  # float32 flash kernel (attention_split.hip): SD-1.5's head dims and SDXL's 64
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 6
+#define GMD_ABI_VERSION 7
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -237,6 +237,25 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
                 const float* bias, const float* rowbias, int64_t ldrb, const void* residual, float alpha,
                 float* colstats, int colstats_bucket,
                 void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
+
+/* conv3x3 whose output goes straight into a GroupNorm (+SiLU): ResnetBlock2D's conv1 -> (+ time embedding) -> norm2 -> SiLU
+ * (diffusers ResnetBlock2D.forward; reached through UNet2DConditionModel at stable_diffusion_dual_unet.py:1052, 1083).  On the
+ * 16x16 / 8x8 UNet levels the convolution runs split-K (float32 partial slabs in `workspace`); here the GroupNorm kernel sums
+ * the slabs itself, applies the convolution's epilogue (alpha, bias, rowbias, residual), rounds to the activation type exactly
+ * as the stored tensor would be rounded and normalises from registers: one launch instead of reduce + GroupNorm, the raw
+ * tensor neither written nor re-read.  Ynorm = GroupNorm(conv(X)) [+ SiLU]; Yraw (NULL to skip) = conv(X) as gmd_conv3x3
+ * would store it.  Results are bit-identical to gmd_conv3x3 followed by gmd_groupnorm_fused.
+ * dtype: GMD_BF16 / GMD_F16 (tensors of that type) or GMD_F32S / GMD_F32SW (float32 tensors).  Only launches whose plan is
+ * split-K and whose (sample, group) slice fits the register-resident GroupNorm fuse: gmd_conv3x3_gn_fusable() returns 1 for
+ * exactly those (same arguments; `groups` = GroupNorm groups); for the others gmd_conv3x3_groupnorm returns
+ * GMD_ERR_UNSUPPORTED and the caller issues gmd_conv3x3 + a GroupNorm entry point. */
+int gmd_conv3x3_gn_fusable(int dtype, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode,
+                           int groups, int64_t workspace_bytes);
+int gmd_conv3x3_groupnorm(const void* X, const void* Wt, void* Yraw, void* Ynorm, int dtype,
+                          int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode,
+                          const float* bias, const float* rowbias, int64_t ldrb, const void* residual, float alpha,
+                          int groups, float eps, const float* gamma, const float* beta, int silu,
+                          void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
 
 /* Flash-style attention, bf16 MFMA: O = softmax(scale * Q K^T) V per (batch, head).
  * Q: [B,Nq,*] head h at columns h*D..h*D+D, row stride ldq; K likewise (ldk);

@@ -956,3 +956,68 @@ def test_ff_geglu_fused_matches_two_gemms_and_float64(dtype, M):
     assert rel_err(got.float(), two.float()) < t  # both round H to the 16-bit type once; only the summation order differs
     assert not o.ff_fused_ok(xd[:100], C, min_rows=0) and not o.ff_fused_ok(torch.zeros(128, 640, dtype=dtype, device=DEV), 640, min_rows=0)
     assert o.ff_fused_ok(xd, C) == (M >= o.FUSED_FF_MIN_ROWS)  # the product path takes it only where it fills the chip
+
+
+# B, H, Cin, Cout, split-K expected, accesses per thread class
+CONV_GN_CASES = [(2, 16, 320, 256), (8, 16, 640, 1280), (8, 8, 1280, 1280), (2, 16, 320, 2560), (1, 8, 640, 1280), (16, 8, 320, 2560)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,H,Cin,Cout", CONV_GN_CASES)
+def test_conv3x3_groupnorm_from_splitk_slabs_bit_identical(dtype, B, H, Cin, Cout):
+    """gmd_conv3x3_groupnorm (ResnetBlock2D conv1 -> + time embedding -> norm2 -> SiLU on the 16x16 / 8x8 levels): the GroupNorm
+    kernel sums the split-K slabs itself.  Raw and normalised tensors must equal gmd_conv3x3 + gmd_groupnorm_fused bit for bit,
+    with and without bias / row bias (column offset into a wider matrix) / residual / SiLU; where the launch does not fuse the
+    wrapper falls back to the two calls."""
+    from gm_diffusion import hip_ops as ops
+    from gm_diffusion._native import lib
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
+    W = H
+    x = torch.randn(B, H * W, Cin, generator=g).to(DEV, dtype)
+    w = (torch.randn(Cout, 9 * Cin, generator=g) / math.sqrt(9 * Cin)).to(DEV, dtype)
+    if dtype == torch.float32:
+        w = ops.split_weights(w)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    temb = torch.randn(B, 3 * Cout, generator=g).to(DEV)
+    res = torch.randn(B, H * W, Cout, generator=g).to(DEV, dtype)
+    gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    code = ops._contract_code(x, w, Cin)
+    fus = lib().gmd_conv3x3_gn_fusable(code, B, H, W, Cin, Cout, 1, 0, 0, 32, ops.WORKSPACE_BYTES)
+    cpg_bytes = Cout // 32 * x.element_size()
+    want = cpg_bytes % 16 == 0 and H * W * (cpg_bytes // 16) <= 256 * 12 and B * 32 >= 256
+    assert bool(fus) == want, "every case is split-K; taken when the group slice fits the register-resident kernel and B x G fills the chip"
+    for kw, silu in ((dict(bias=bias, rowbias=(temb, Cout)), True), (dict(bias=bias, residual=res), False), (dict(), True),
+                     (dict(rowbias=temb[:, :Cout].contiguous(), residual=res), True)):
+        y, _, _ = ops.conv3x3(x, w, B, H, W, **kw)
+        yn = ops.groupnorm(y, B, 32, gamma, beta, 1e-5, silu=silu)
+        r1, n1 = ops.conv3x3_groupnorm(x, w, B, H, W, 32, gamma, beta, 1e-5, silu=silu, want_raw=True, **kw)
+        r0, n0 = ops.conv3x3_groupnorm(x, w, B, H, W, 32, gamma, beta, 1e-5, silu=silu, **kw)
+        assert r0 is None and torch.equal(r1, y) and torch.equal(n1, yn) and torch.equal(n0, yn)
+        if cpg_bytes % 16 == 0 and H * W * (cpg_bytes // 16) <= 256 * 12:  # the entry point itself also runs small batches
+            r2 = torch.empty_like(y)
+            n2 = torch.empty_like(y)
+            rb = kw.get("rowbias")
+            rb_ptr, rb_ld = ops._rowbias(rb)
+            ops.check(lib().gmd_conv3x3_groupnorm(x.data_ptr(), w.data_ptr(), r2.data_ptr(), n2.data_ptr(), code, B, H, W, Cin, Cout, 1, 0, 0,
+                                                  ops._ptr(kw.get("bias")), rb_ptr, rb_ld, ops._ptr(kw.get("residual")), float(getattr(w, "_alpha", 1.0)),
+                                                  32, 1e-5, gamma.data_ptr(), beta.data_ptr(), int(silu), ops._workspace(x.device).data_ptr(),
+                                                  ops.WORKSPACE_BYTES, torch.cuda.current_stream().cuda_stream), "gmd_conv3x3_groupnorm")
+            assert torch.equal(r2, y) and torch.equal(n2, yn)
+        assert torch.isfinite(yn.float()).all()
+
+
+def test_conv3x3_groupnorm_refuses_unfusable_launch():
+    """Called directly on a launch whose plan is not split-K (64x64 level) the entry point fails loudly instead of running."""
+    from gm_diffusion import hip_ops as ops
+    from gm_diffusion._native import lib
+    B, H, C = 2, 64, 320
+    x = torch.randn(B, H * H, C, device=DEV).bfloat16()
+    w = (torch.randn(C, 9 * C, device=DEV) * 0.02).bfloat16()
+    gamma = torch.ones(C, device=DEV)
+    yn = torch.empty_like(x)
+    assert lib().gmd_conv3x3_gn_fusable(ops.GMD_BF16, B, H, H, C, C, 1, 0, 0, 32, ops.WORKSPACE_BYTES) == 0
+    rc = lib().gmd_conv3x3_groupnorm(x.data_ptr(), w.data_ptr(), None, yn.data_ptr(), ops.GMD_BF16, B, H, H, C, C, 1, 0, 0, None, None, 0, None,
+                                     1.0, 32, 1e-5, gamma.data_ptr(), gamma.data_ptr(), 1, ops._workspace(x.device).data_ptr(),
+                                     ops.WORKSPACE_BYTES, torch.cuda.current_stream().cuda_stream)
+    assert rc == 3 and b"does not fuse" in lib().gmd_last_error()
+    torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3n; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3z; mkdir -p $O
 # 1. the default bench command, un-profiled, then under the kernel trace
 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err
 rm -rf /tmp/prof; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_line_profiled.json 2> $O/prof.err
