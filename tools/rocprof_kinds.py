@@ -16,7 +16,10 @@ def add(kind, ns):
 last_kind = None
 for s, e, name in rows:
     d = e - s
-    if "splitk_reduce" in name:
+    if "spin_kernel" in name:  # torch.cuda._sleep: the host head start of bench.py's instrumented step, not workload
+        continue
+    if "splitk_reduce" in name or "gn_slab_kernel" in name:  # (gn_slab: reduction + GroupNorm of gmd_conv3x3_groupnorm, timed
+        # by bench.py as part of that conv3x3 call)
         if last_kind:  # belongs to the GEMM / conv launch it completes: add time, not a launch
             agg[last_kind][1] += d
         continue
