@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 
 import torch
 
@@ -600,8 +601,49 @@ def side_stream(device):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     s = _SIDE_STREAMS.get(key)
     if s is None:
-        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        s = _SIDE_STREAMS[key] = _stream_beside_current(device)
     return s
+
+
+_SPIN_TICKS = 1_000_000  # ~0.4 ms of torch.cuda._sleep at the MI355X shader clock
+
+
+def _stream_beside_current(device, candidates=8):
+    """A new stream that really runs BESIDE the current one.  Of the streams a process creates, about every fourth lands on the
+    hardware queue of the null stream (tools/stream_queue_probe.py: pool streams 6, 10, 14, ... of a fresh process), so the
+    first candidate is not taken on trust: one single-thread spinning kernel on each of the two streams must take the time of one
+    spin, not of two.  ~3 ms, once per device and process; falls back to the first candidate when the probe cannot run."""
+    first = torch.cuda.Stream(device=device)
+    try:
+        with torch.cuda.device(device):
+            if torch.cuda.is_current_stream_capturing():
+                return first
+            cur = torch.cuda.current_stream()
+
+            def wall(fn):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+
+            def both(st):
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(_SPIN_TICKS)
+                torch.cuda._sleep(_SPIN_TICKS)
+
+            torch.cuda._sleep(_SPIN_TICKS)
+            one = min(wall(lambda: torch.cuda._sleep(_SPIN_TICKS)) for _ in range(2))
+            st = first
+            for _ in range(candidates):
+                both(st)
+                if min(wall(lambda: both(st)) for _ in range(2)) < 1.5 * one:
+                    return st
+                st = torch.cuda.Stream(device=device)
+            del cur
+    except Exception:  # pragma: no cover -- the probe is an optimisation, never a reason to fail
+        pass
+    return first
 
 
 def dup_batch(t):

@@ -180,6 +180,37 @@ def test_pipelines_share_one_side_stream_per_device():
             assert torch.equal(o[0], outs[name][0]) and torch.equal(o[1], outs[name][1])
 
 
+def test_side_stream_is_chosen_by_a_concurrency_probe():
+    """About every fourth stream a process creates shares the hardware queue of the null stream (tools/stream_queue_probe.py);
+    hip_ops.side_stream must hand out one that really runs beside the current stream, however many streams came before it."""
+    import time
+    from gm_diffusion import hip_ops as ops
+    saved = dict(ops._SIDE_STREAMS)
+    try:
+        for n_before in (0, 1, 2, 3):  # one of these offsets puts the first candidate on the null stream's queue
+            junk = [torch.cuda.Stream() for _ in range(n_before)]
+            ops._SIDE_STREAMS.clear()
+            s = ops.side_stream(DEV)
+
+            def wall(fn):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+                return time.perf_counter() - t0
+
+            def both():
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(2_000_000)
+                torch.cuda._sleep(2_000_000)
+
+            both()
+            one = min(wall(lambda: torch.cuda._sleep(2_000_000)) for _ in range(3))
+            two = min(wall(both) for _ in range(3))
+            assert two < 1.5 * one, f"side stream after {n_before} other streams is serialised with the current stream ({two / one:.2f}x)"
+            del junk
+    finally:
+        ops._SIDE_STREAMS.clear()
+        ops._SIDE_STREAMS.update(saved)
+
+
 def test_dual_pipeline_dpm_solver_on_device_matches_oracle():
     """the DPM-Solver++ swap the reference makes (formal_improved.py:195) runs the HIP models through
     the generic scheduler protocol; fp32 latents must match the oracle loop within the north-star tolerance."""
