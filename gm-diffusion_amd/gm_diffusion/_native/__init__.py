@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 GMD_F32, GMD_BF16, GMD_F16, GMD_F32S, GMD_F32SW = 0, 1, 2, 3, 4
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -33,6 +33,8 @@ SIGNATURES = {
     "gmd_discretize_u16": [P, P, P, L, P],
     "gmd_quantize_u8": [P, P, L, P],
     "gmd_rgbe_encode": [P, P, L, P],
+    "gmd_rgbe_rle_bound": [I, I],
+    "gmd_rgbe_rle_encode": [P, I, I, P, L, P],
     "gmd_latent_step": [P, P, P, P, P, P, I, L, I, F, P, F, I, F, F, F, F, F, P, P, P, P],
     "gmd_dpm_step": [P, P, P, I, L, I, F, P, F, I, F, F, F, F, F, F, F, F, P, P, P, P],
     "gmd_ddpm_step": [P, P, P, I, L, I, F, P, F, F, F, I, F, F, F, F, F, F, P, P, P],
@@ -64,7 +66,7 @@ SIGNATURES = {
     "gmd_cast": [P, I, P, I, L, P],
     "gmd_dup_batch": [P, P, L, P],
 }
-_RESTYPES = {"gmd_last_error": c_char_p}
+_RESTYPES = {"gmd_last_error": c_char_p, "gmd_rgbe_rle_bound": c_int64}
 
 
 class HipExtensionError(RuntimeError):

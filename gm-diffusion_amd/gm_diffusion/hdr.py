@@ -52,11 +52,37 @@ def _f32(x):
 # ------------------------------------------------------------------------------------------------
 # file writers: the reference uses cv2.imwrite("*.hdr") / PIL; cv2 is absent here
 # ------------------------------------------------------------------------------------------------
-def save_hdr_image(hdr_file_rgb, path):
+def rgbe_scanlines(px, compression="rle"):
+    """Bytes that follow the header of a Radiance picture for RGBE pixels ``px`` ([H, W, 4] uint8 host array): run-length
+    framed scanlines ("rle": what OpenCV's encoder behind cv2.imwrite writes by default; host function gmd_rgbe_rle_encode of
+    the C ABI) or flat pixels ("none": cv2's IMWRITE_HDR_COMPRESSION_NONE)."""
+    import ctypes
+
+    import numpy as np
+
+    from ._native import check, lib
+    px = np.ascontiguousarray(px, dtype=np.uint8)
+    if px.ndim != 3 or px.shape[-1] != 4:
+        raise ValueError("rgbe_scanlines expects [H, W, 4] bytes")
+    if compression == "none":
+        return px.tobytes()
+    if compression != "rle":
+        raise ValueError("compression must be 'rle' or 'none'")
+    h, w = int(px.shape[0]), int(px.shape[1])
+    cap = int(lib().gmd_rgbe_rle_bound(h, w))
+    out = np.empty(max(cap, 1), np.uint8)
+    n = ctypes.c_int64(0)
+    check(lib().gmd_rgbe_rle_encode(px.ctypes.data, h, w, out.ctypes.data, cap, ctypes.addressof(n)), "gmd_rgbe_rle_encode")
+    return out[: n.value].tobytes()
+
+
+def save_hdr_image(hdr_file_rgb, path, compression="rle"):
     """Write one Radiance RGBE picture.  ``hdr_file_rgb``: [H,W,3] float32 device tensor, already divided by
     (qmax+1) and in RGB order (= ``out['hdr_file'][i]``); this is what the reference's ``save_hdr_image``
     (generate_hdr.py:27-30) hands to ``cv2.imwrite`` after its BGR swap.  Pixels are encoded on the device
-    (gmd_rgbe_encode); scanlines are written flat (uncompressed), which every Radiance reader accepts.
+    (gmd_rgbe_encode); scanlines are run-length framed on the host like OpenCV's writer does by default
+    (``compression="none"`` writes them flat).  cv2 is absent in this image: header text and framing follow the published
+    Radiance format, not a byte comparison with cv2's output.
     Negative values (possible with the unclamped Eq. 1) are stored as 0: RGBE has no sign."""
     x = hdr_file_rgb.contiguous()
     if x.dim() != 3 or x.shape[-1] != 3:
@@ -66,7 +92,7 @@ def save_hdr_image(hdr_file_rgb, path):
     with open(path, "wb") as f:
         f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n")
         f.write(f"-Y {h} +X {w}\n".encode())
-        f.write(px.tobytes())
+        f.write(rgbe_scanlines(px.reshape(h, w, 4), compression))
 
 
 def save_png_u8(u8_rgb, path):

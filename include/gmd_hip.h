@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 7
+#define GMD_ABI_VERSION 8
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -96,6 +96,12 @@ int gmd_discretize_u16(const float* in, float* out_float, uint16_t* out_codes, i
 /* Radiance RGBE pixels of float RGB [npix,3] -> [npix,4] bytes (Ward's float2rgbe, the encoder behind
  * cv2.imwrite("*.hdr"), scripts/inference/generate_hdr.py:27-30); negative components are stored as 0 */
 int gmd_rgbe_encode(const float* rgb, uint8_t* out, int64_t npix, gmd_stream_t stream);
+/* HOST function (no device work): run-length framing of RGBE scanlines for a Radiance .hdr file, the form OpenCV's encoder
+ * behind cv2.imwrite("*.hdr") (generate_hdr.py:27-30) writes by default.  rgbe: host [H][W][4] bytes from gmd_rgbe_encode;
+ * out: host buffer of at least gmd_rgbe_rle_bound(H, W) bytes; *out_bytes = bytes to write after the header.  Widths < 8 or
+ * > 32767 come back flat, as the format prescribes. */
+int64_t gmd_rgbe_rle_bound(int H, int W);
+int gmd_rgbe_rle_encode(const uint8_t* rgbe, int H, int W, uint8_t* out, int64_t capacity, int64_t* out_bytes);
 /* generate_hdr.py:244-245 (x*255).astype(uint8) */
 int gmd_quantize_u8(const float* in, uint8_t* out, int64_t n, gmd_stream_t stream);
 

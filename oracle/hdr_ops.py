@@ -173,6 +173,72 @@ def rgbe_encode(rgb):
     return out
 
 
+def rgbe_rle_scanlines(px):
+    """Run-length framing of RGBE scanlines as the Radiance format defines it and rgbe.c's RGBE_WritePixels_RLE /
+    RGBE_WriteBytes_RLE write it -- the writer inside OpenCV's HDR encoder, which the reference reaches through cv2.imwrite at
+    generate_hdr.py:27-30 (cv2 absent here: restated from the published format, unpinned against cv2's bytes).  ``px``:
+    [H, W, 4] uint8.  Pure-Python loops: small cases only."""
+    px = np.ascontiguousarray(px, np.uint8)
+    h, w = px.shape[0], px.shape[1]
+    if w < 8 or w > 0x7FFF:
+        return px.tobytes()
+    out = bytearray()
+    for y in range(h):
+        out += bytes((2, 2, w >> 8, w & 0xFF))
+        for c in range(4):
+            data = px[y, :, c].tolist()
+            cur = 0
+            while cur < w:
+                beg, run, old = cur, 0, 0
+                while run < 4 and beg < w:
+                    beg += run
+                    old = run
+                    run = 1
+                    while beg + run < w and run < 127 and data[beg] == data[beg + run]:
+                        run += 1
+                if old > 1 and old == beg - cur:
+                    out += bytes((128 + old, data[cur]))
+                    cur = beg
+                while cur < beg:
+                    m = min(beg - cur, 128)
+                    out.append(m)
+                    out += bytes(data[cur:cur + m])
+                    cur += m
+                if run >= 4:
+                    out += bytes((128 + run, data[beg]))
+                    cur += run
+    return bytes(out)
+
+
+def rgbe_rle_decode(buf, h, w):
+    """Reader for :func:`rgbe_rle_scanlines` (the adaptive run-length scheme any Radiance reader implements): -> [H, W, 4] uint8."""
+    buf = bytes(buf)
+    if w < 8 or w > 0x7FFF:
+        return np.frombuffer(buf, np.uint8).reshape(h, w, 4).copy()
+    out = np.zeros((h, w, 4), np.uint8)
+    p = 0
+    for y in range(h):
+        assert buf[p] == 2 and buf[p + 1] == 2 and (buf[p + 2] << 8 | buf[p + 3]) == w, "bad scanline header"
+        p += 4
+        for c in range(4):
+            x = 0
+            while x < w:
+                n = buf[p]
+                p += 1
+                if n > 128:
+                    n -= 128
+                    out[y, x:x + n, c] = buf[p]
+                    p += 1
+                else:
+                    assert n > 0
+                    out[y, x:x + n, c] = np.frombuffer(buf[p:p + n], np.uint8)
+                    p += n
+                x += n
+            assert x == w, "run crosses the end of a scanline"
+    assert p == len(buf)
+    return out
+
+
 def rgbe_decode(px):
     """Inverse of :func:`rgbe_encode` (Ward's ``rgbe2float`` without the +0.5 bias OpenCV also omits)."""
     px = np.asarray(px)

@@ -504,11 +504,16 @@ def test_rgbe_encode_bit_exact_and_file(tmp_path):
     got = o.rgbe_encode(x.to(DEV)).cpu().numpy()
     assert np.array_equal(got, H.rgbe_encode(x.numpy()))  # byte work: bit exact
     path = tmp_path / "a.hdr"
-    hdr.save_hdr_image(x.to(DEV), str(path))
+    hdr.save_hdr_image(x.to(DEV), str(path), compression="none")
     raw = open(path, "rb").read()
     head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 37 +X 53\n"
     assert raw.startswith(head) and len(raw) == len(head) + 37 * 53 * 4
     assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(37, 53, 4), got)
+    # default: run-length framed scanlines (what cv2.imwrite writes): the oracle's restatement byte for byte, and readable back
+    hdr.save_hdr_image(x.to(DEV), str(path))
+    raw = open(path, "rb").read()
+    assert raw.startswith(head) and raw[len(head):] == H.rgbe_rle_scanlines(got.reshape(37, 53, 4))
+    assert np.array_equal(H.rgbe_rle_decode(raw[len(head):], 37, 53), got.reshape(37, 53, 4))
 
 
 @pytest.mark.parametrize("D,N", [(64, 77), (32, 77), (64, 200)])

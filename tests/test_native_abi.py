@@ -101,3 +101,30 @@ def test_export_surface_matches_reference():
               "linear_scale_tmo", "random_tmo_cuda", "tmo_cuda"):
         assert hasattr(S, n)
     assert issubclass(P.StableDiffusionDualUNetImprovedPipeline, P.StableDiffusionDualUNetPipeline)
+
+
+def test_host_rgbe_run_length_encoder_equals_oracle():
+    """gmd_rgbe_rle_encode is a HOST function of the C ABI (no device work): byte-identical to the oracle's restatement of the
+    Radiance scanline framing on random, run-heavy, ragged and flat-width inputs; capacity is checked."""
+    import ctypes
+
+    import numpy as np
+
+    from gm_diffusion import hdr
+    from gm_diffusion._native import lib
+    from oracle import hdr_ops as H
+    rng = np.random.default_rng(11)
+    for h, w in ((1, 8), (3, 53), (2, 128), (2, 129), (4, 300), (2, 7), (0, 16), (1, 40000)):
+        px = rng.integers(0, 4, (h, w, 4), dtype=np.uint8) * rng.integers(0, 2, (h, w, 1), dtype=np.uint8)  # many runs
+        if h and w > 200:
+            px[0, 10:160, 2] = np.arange(150, dtype=np.uint8)  # more than 128 literals
+        got = hdr.rgbe_scanlines(px)
+        assert got == H.rgbe_rle_scanlines(px), (h, w)
+        if h:
+            assert np.array_equal(H.rgbe_rle_decode(got, h, w), px)
+    assert hdr.rgbe_scanlines(px, "none") == px.tobytes()
+    px = np.zeros((2, 16, 4), np.uint8)
+    out = np.zeros(8, np.uint8)
+    n = ctypes.c_int64(0)
+    assert lib().gmd_rgbe_rle_encode(px.ctypes.data, 2, 16, out.ctypes.data, 8, ctypes.addressof(n)) == 1  # GMD_ERR_INVALID
+    assert b"smaller than gmd_rgbe_rle_bound" in lib().gmd_last_error()

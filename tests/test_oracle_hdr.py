@@ -90,3 +90,28 @@ def test_rgbe_known_answers_and_roundtrip():
     d = H.rgbe_decode(H.rgbe_encode(y))
     # 8-bit mantissa relative to the pixel maximum, truncation: error < max/128 per component
     assert np.all(y - d >= 0) and np.all(y - d <= y.max(-1, keepdims=True) / 128 + 1e-6)
+
+
+def test_rgbe_run_length_scanlines_known_answers_and_roundtrip():
+    """The scanline framing of Radiance pictures (oracle restatement of rgbe.c's writer; cv2 absent): hand-checked byte strings
+    for the run / literal / short-run cases, flat output outside 8 <= width <= 32767, and decode(encode(x)) == x."""
+    w = 16
+    line = np.zeros((1, w, 4), np.uint8)
+    line[0, :, 0] = [7] * 16                                        # one long run
+    line[0, :, 1] = list(range(16))                                 # literals only
+    line[0, :, 2] = [1, 1, 5, 5, 5, 5, 5, 2, 3, 3, 3, 9, 9, 9, 9, 4]  # short run, long run, literals (a 3-run stays literal), run, tail
+    line[0, :, 3] = [128] * 5 + [129] * 11
+    got = H.rgbe_rle_scanlines(line)
+    want = bytes([2, 2, 0, 16]) + bytes([128 + 16, 7]) + bytes([16] + list(range(16))) \
+        + bytes([128 + 2, 1, 128 + 5, 5, 4, 2, 3, 3, 3, 128 + 4, 9, 1, 4]) + bytes([128 + 5, 128, 128 + 11, 129])
+    assert got == want
+    assert np.array_equal(H.rgbe_rle_decode(got, 1, w), line)
+    rng = np.random.default_rng(5)
+    for h, w in ((3, 8), (2, 200), (5, 131), (1, 300)):
+        px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        px[:, w // 3: w // 3 + 140, 3] = 130   # a run longer than 127 and literals longer than 128 in one line
+        px[0, :, 0] = 9
+        enc = H.rgbe_rle_scanlines(px)
+        assert np.array_equal(H.rgbe_rle_decode(enc, h, w), px)
+    small = rng.integers(0, 256, (4, 7, 4), dtype=np.uint8)
+    assert H.rgbe_rle_scanlines(small) == small.tobytes()  # width < 8: flat
