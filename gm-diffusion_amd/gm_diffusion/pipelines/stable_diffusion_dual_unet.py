@@ -61,6 +61,7 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
     # latents_{i+1}).  Measured on MI355X (bench.py): eager launches 3.04 vs 3.04 images/s (the host, ~10 us per launch,
     # cannot keep two streams fed); with each forward replayed from a captured HIP graph 3.04 -> 3.86 images/s.
     overlap_streams = True
+    _step_probe = None  # test hook: callable(i, sdr_latents, gm_latents) after every loop iteration
 
     def __init__(self, vae, text_encoder, tokenizer, unet, gm_unet, scheduler, safety_checker, feature_extractor,
                  image_encoder=None, requires_safety_checker: bool = True):
@@ -235,6 +236,13 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                                                  return_dict=False)[0]
                     gm_latents = self.gm_scheduler.step(gm_noise_pred, t, gm_latents, **extra_step_kwargs, return_dict=False)[0]
 
+                if self._step_probe is not None:
+                    # test hook (tests/test_northstar_gpu.py): the reference's callback block is commented out
+                    # (stable_diffusion_dual_unet.py:1095-1103) and its legacy callback sees the SDR latents only; the probe
+                    # gets BOTH latents of iteration i after joining the two streams (this serialises them: not for timing)
+                    if fused:
+                        torch.cuda.synchronize(latents.device)
+                    self._step_probe(i, latents, gm_latents)
                 if i == len(timesteps) - 1 or ((i + 1) > num_warmup_steps and (i + 1) % self.scheduler.order == 0):
                     progress_bar.update()
                     if callback is not None and i % callback_steps == 0:

@@ -84,8 +84,41 @@ def fixture_dual_tiny_rescale():
     return _np(dict(prompt_embeds=pos, negative_prompt_embeds=neg, latents=lat, sdr_out=sdr, gm_out=gm))
 
 
+DUAL_SD15_RECORD_EVERY = 5  # iterations 0, 5, ..., 50 of the 51 are kept
+
+
+def fixture_dual_sd15_512(steps=50):
+    """The north-star path at its own width (BASELINE config 2 with one prompt): SD-1.5-width SDR + GM UNets, 64x64 latent
+    (512x512), ``steps`` PNDM steps (steps + 1 iterations), CFG 7.5, float32 -- stable_diffusion_dual_unet.py:1040-1093 as
+    formal_improved.py:199 runs it.  ~150 CPU UNet evaluations: minutes.  Inputs are reproducible by seed (build_unet("sd15", 4 | 8),
+    make_inputs(1, 64, 64), build_vae("sd15")), so only outputs are stored: the final latent pair, every 5th iteration's pair and a
+    128x128 crop of the decoded tail (generate_hdr.py:225-265) from the SD-1.5-width VAE decoder."""
+    unet, gm_unet = build_unet("sd15", 4), build_unet("sd15", 8)
+    pos, neg, lat = make_inputs(1, 64, 64)
+    rec = []
+    sdr, gm = pipelines.dual_loop(unet, gm_unet, schedulers.PNDMScheduler(), pos, neg, lat,
+                                  num_inference_steps=steps, guidance_scale=7.5, record=rec)
+    idx = list(range(0, len(rec), DUAL_SD15_RECORD_EVERY))
+    d = dict(steps=np.int64(steps), record_index=np.asarray(idx, dtype=np.int64), sdr_out=sdr, gm_out=gm,
+             sdr_per_step=torch.stack([rec[i][0] for i in idx]), gm_per_step=torch.stack([rec[i][1] for i in idx]),
+             latents_checksum=np.float64(lat.double().sum().item()), embeds_checksum=np.float64(pos.double().sum().item()))
+    del unet, gm_unet
+    tail = pipelines.decode_tail(build_vae("sd15"), sdr, gm, qmax=99)
+    c = slice(192, 320)
+    for k in ("sdr_dec", "gm_dec"):  # NCHW
+        d["tail_" + k + "_crop"] = tail[k][:, :, c, c]
+    for k in ("sdr", "gm", "hdr", "hdr_norm", "sdr_u8", "gm_u8"):  # NHWC
+        if k in tail:
+            d["tail_" + k + "_crop"] = tail[k][:, c, c, :]
+    return _np(d)
+
+
 PIPELINE_FIXTURES = {
     "gm_tiny": fixture_gm_tiny,
     "dual_tiny": fixture_dual_tiny,
     "dual_tiny_rescale": fixture_dual_tiny_rescale,
+}
+# minutes of CPU each: only regenerated on request (make_golden.py --slow)
+SLOW_PIPELINE_FIXTURES = {
+    "dual_sd15_512": fixture_dual_sd15_512,
 }

@@ -13,7 +13,10 @@ Part 2 (``pipeline_oracle_*.npz``) stores whole-pipeline vectors produced by the
 oracle itself (seeded tiny random-weight UNets): they pin the product's host
 logic / GPU path to the oracle, not the oracle to diffusers (parity unpinned).
 
-Usage:  python oracle/make_golden.py [--reference /root/reference]
+Part 3 (``--slow``; ``pipeline_oracle_dual_sd15_512.npz``) is the north-star path at its own width -- the dual-UNet loop with
+both SD-1.5-width UNets at 512x512, 50 PNDM steps -- from the same oracle; minutes of CPU, regenerated only on request.
+
+Usage:  python oracle/make_golden.py [--reference /root/reference] [--slow]
 """
 from __future__ import annotations
 
@@ -89,12 +92,13 @@ def make_hdr_reference(ref_root):
     print("wrote hdr_ops_reference.npz with", len(out), "arrays")
 
 
-def make_pipeline_vectors():
+def make_pipeline_vectors(slow=False):
     sys.path.insert(0, ROOT)
     from oracle import fixtures
 
     os.makedirs(GOLD, exist_ok=True)
-    for name, fn in fixtures.PIPELINE_FIXTURES.items():
+    todo = fixtures.SLOW_PIPELINE_FIXTURES if slow else fixtures.PIPELINE_FIXTURES
+    for name, fn in todo.items():
         out = fn()
         np.savez_compressed(os.path.join(GOLD, f"pipeline_oracle_{name}.npz"), **out)
         print("wrote pipeline_oracle_%s.npz" % name, {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
@@ -104,7 +108,17 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--skip-pipeline", action="store_true")
+    ap.add_argument("--slow", action="store_true",
+                    help="only the full-width fixtures (pipeline_oracle_dual_sd15_512.npz: ~150 SD-1.5 UNet evaluations on the CPU, minutes)")
     a = ap.parse_args()
+    if a.slow:
+        import time
+
+        torch.set_num_threads(os.cpu_count() or 1)
+        t0 = time.time()
+        make_pipeline_vectors(slow=True)
+        print("slow fixtures: %.0f s on %d threads" % (time.time() - t0, torch.get_num_threads()))
+        sys.exit(0)
     if os.path.isdir(a.reference):
         make_hdr_reference(a.reference)
     else:
