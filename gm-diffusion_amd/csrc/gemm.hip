@@ -886,6 +886,330 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, ping-pong form (round 4): ONE workgroup per CU on a 256 x (32 TN) tile -- 8 consumer waves (wave tile
+// 64 x 16 TN, the two waves of every SIMD staggered by one barrier so that one multiplies while the other reads fragments)
+// and LW loader waves that do nothing but issue the LDS-DMA of later tiles.
+//
+// Why (in-kernel stamps, tools/pp_diag.py, conv 8x64x64 640->320):
+//  * the ring kernel above is bound by what a CU can pull from L2 into its LDS (~35 B/clk: 97 us with the MFMAs removed =
+//    6.5 MB per CU at 67 GB/s); a 256 x 160 tile needs 52 KB per K step where two co-resident 128 x 160 tiles need 72 KB;
+//  * an LDS-DMA instruction BLOCKS its wave while the CU's memory queue is full -- ~90 cycles per piece with four waves
+//    issuing at once.  In the first version of this kernel the consumers issued the DMA in their read segments: 285 cycles of
+//    blocked issue + 280 of fragment reads + the vmcnt wait = 700 cycles opposite a 380-cycle MFMA segment, i.e. the matrix
+//    pipe idled half of every interval.  Loader waves take that blocking off the consumers' path.
+//
+//   consumer, per K step kt (stage kt % 3):   R0: 4 + TN ds_read_b128 (k 0..31) ; lgkmcnt(0) ; barrier
+//                                             C0: 4 x TN MFMAs                   ; barrier
+//                                             R1: reads (k 32..63) ; lgkmcnt(0)  ; barrier
+//                                             C1: 4 x TN MFMAs                   ; barrier
+//     waves 4-7 execute one extra barrier before the loop, waves 0-3 one after it: in every barrier interval one group reads
+//     and the other multiplies (the 8-phase template of the programming guide, cut for 64 x 16 TN wave tiles);
+//   loader, per K step kt:  four intervals, each: a quarter of tile kt+2's pieces ; [last: vmcnt(tile kt+1 landed)] ; barrier
+//
+// LDS hazards, by global barrier number (prologue barrier = #0; waves 0-3 and the loaders end their four segments of step kt
+// at #4kt+1..#4kt+4, waves 4-7 one later): the last reads of tile kt-1 (waves 4-7, R1) have RETURNED (lgkmcnt(0)) before they
+// arrive at #4kt; the DMA of tile kt+2 into that stage is issued after #4kt.  A loader's pieces of tile kt+1 have landed
+// (counted vmcnt) before it arrives at #4kt+4, and the first read of tile kt+1 (waves 0-3, R0) is issued after #4kt+4.
+// ------------------------------------------------------------------------------------------------
+template <typename HT, bool CONV, int TN>
+__global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
+    constexpr int WN = 2, NCONS = 8, LW = 4, TM = 4, NST = 3;
+    constexpr int BM = 256, BN = WN * TN * 16;
+    constexpr int RPP = LW * 8;                     // 32 tile rows per staging pass (8 rows per loader-wave instruction)
+    constexpr int NA = BM / RPP;                    // 8 A pieces per loader wave and tile
+    constexpr int NW = BN / RPP;                    // 5 / 4 W pieces
+    constexpr int NP = NA + NW;                     // pieces per loader wave and tile
+    static_assert(BN % RPP == 0, "W tile rows must be whole staging passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kStage = (BM + BN) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+    const bool loader = wuni >= NCONS;
+    const bool late = wuni >= 4 && !loader;         // the staggered consumer group (SIMD partners of waves 0-3)
+    int m0, n0;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tiles_n = (p.N + BN - 1) / BN;
+        const int mt = L / tiles_n;
+        m0 = mt * BM;
+        n0 = (L - mt * tiles_n) * BN;
+    }
+    const int z = p.ksplit > 1 ? 0 : blockIdx.z;
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    const int nk_total = p.K / BK;
+    const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * per;
+    const int nk = (kt_begin + per <= nk_total ? per : nk_total - kt_begin);
+
+    // end of a segment: nothing of it may sink below the barrier, nothing of the next may rise above it
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#ifdef GMD_PP_DIAG
+    // diagnostic build only (tools/dbg/libgmd_ppdiag.so): where a wave's loop time goes.  Stamps go to the workspace, which no
+    // other code of this launch reads.  Never timed as a kernel: the stamps' lgkmcnt(0) forbid overlaps the product has.
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = 0, dreal0 = 0, dtime0 = 0;
+    auto stamp_now = [&]() {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    auto diag_begin = [&]() {
+        dprev = stamp_now();
+        dtime0 = dprev;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dreal0)::"memory");
+    };
+    auto diag_end = [&]() {
+        unsigned long long dreal1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dreal1)::"memory");
+        dg[7] = dreal1 - dreal0;  // 100 MHz ticks
+        if (p.ws && lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + ((size_t)blockIdx.x * (NCONS + LW) + wid) * 10;
+            for (int k = 0; k < 8; ++k) o[k] = dg[k];
+            o[8] = dprev - dtime0;
+            o[9] = (unsigned long long)nk;
+        }
+    };
+#define PP_STAMP(k) { const unsigned long long t_ = stamp_now(); dg[k] += t_ - dprev; dprev = t_; }
+#else
+#define PP_STAMP(k)
+#endif
+
+    if (loader) {
+        // ---------------------------------------------------------------- loader waves: LDS-DMA only
+        const int lw = wuni - NCONS;                                  // 0 .. LW-1
+        const int ltid = tid - NCONS * 64;
+        const int srow = ltid >> 3;                                   // 0 .. 31
+        const int chunk = (ltid & 7) ^ ((srow >> 1) & 7);             // swizzled SOURCE chunk (RPP is a multiple of 16)
+        unsigned aoff[NA], woff[NW];
+        int pb[NA], py[NA], px[NA];
+        bool pv[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + srow + RPP * i;
+            pv[i] = m < p.M;
+            pb[i] = py[i] = px[i] = 0;
+            if (CONV) {
+                if (pv[i]) {
+                    const int hw = p.Hout * p.Wout;
+                    if (((hw & (hw - 1)) | (p.Wout & (p.Wout - 1))) == 0) {
+                        const int sh = __builtin_ctz(hw), sw = __builtin_ctz(p.Wout);
+                        pb[i] = m >> sh;
+                        const int rem = m & (hw - 1);
+                        py[i] = rem >> sw;
+                        px[i] = rem & (p.Wout - 1);
+                    } else {
+                        pb[i] = m / hw;
+                        const int rem = m - pb[i] * hw;
+                        py[i] = rem / p.Wout;
+                        px[i] = rem - py[i] * p.Wout;
+                    }
+                }
+                aoff[i] = kOOB;
+            } else {
+                aoff[i] = pv[i] ? (unsigned)m * (unsigned)p.lda * 2u + (unsigned)chunk * 16u : kOOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = n0 + srow + RPP * i;
+            woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u + (unsigned)chunk * 16u : kOOB;
+        }
+        int tap = 0, c0 = 0, cb0 = 0;
+        bool newtap = true;
+        if (CONV) {
+            const int sb = p.cblk / BK, per_cb = 9 * sb;
+            const int cbi = kt_begin / per_cb, rem = kt_begin - cbi * per_cb;
+            tap = rem / sb;
+            cb0 = cbi * p.cblk;
+            c0 = cb0 + (rem - tap * sb) * BK;
+        }
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+        u32x4 dA, dW;
+        {
+            const uint64_t ba = (uint64_t)((const bf16_t*)p.A + (int64_t)z * p.sA), bw = (uint64_t)((const bf16_t*)p.W + (int64_t)z * p.sW);
+            dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+            dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+        }
+        auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                         :
+                         : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                         : "memory", "m0");
+#pragma clang diagnostic pop
+        };
+        // quarter Q of one tile's NP pieces (pieces are numbered A passes first, then W passes); Q == 4: the whole tile
+        auto dma_part = [&](auto QC, int kt, int stage_idx) {
+            constexpr int Q = decltype(QC)::value;
+            constexpr int lo = Q == 4 ? 0 : Q * NP / 4, hi = Q == 4 ? NP : (Q + 1) * NP / 4;
+            unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
+            unsigned abytes = kbytes;
+            if (CONV) {
+                if ((Q == 0 || Q == 4) && newtap) {
+                    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) aoff[i] = conv_tap_offset<CONV>(p, pv[i], pb[i], py[i], px[i], ky, kx, chunk);
+                    newtap = false;
+                }
+                abytes = (unsigned)c0 * 2u;
+                kbytes = (unsigned)(tap * p.Cin + c0) * 2u;
+            }
+            const unsigned stage = lds_base + (unsigned)stage_idx * kStage + (unsigned)lw * (8 * 128);
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (i >= lo && i < hi) dma16(dA, stage + i * (RPP * 128), aoff[i], abytes);
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                if (NA + i >= lo && NA + i < hi) dma16(dW, stage + BM * 128 + i * (RPP * 128), woff[i], kbytes);
+            if (CONV && (Q == 3 || Q == 4)) {
+                c0 += BK;
+                if (c0 >= cb0 + p.cblk) {
+                    c0 = cb0;
+                    ++tap;
+                    newtap = true;
+                    if (tap == 9) { tap = 0; cb0 += p.cblk; c0 = cb0; }
+                }
+            }
+        };
+        if (nk > 0) {  // block-uniform
+            dma_part(IntC<4>{}, 0, 0);
+            if (nk > 1) {
+                dma_part(IntC<4>{}, 1, 1);
+                wait_vmcnt<NP>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            seg_barrier();  // #0: tile 0 is in LDS
+            int st_fill = 2;
+#ifdef GMD_PP_DIAG
+            diag_begin();
+#endif
+            for (int kt = 0; kt < nk; ++kt) {
+                const bool more = kt + 2 < nk;
+                if (more) dma_part(IntC<0>{}, kt + 2, st_fill);
+                PP_STAMP(1)
+                seg_barrier();
+                PP_STAMP(3)
+                if (more) dma_part(IntC<1>{}, kt + 2, st_fill);
+                PP_STAMP(1)
+                seg_barrier();
+                PP_STAMP(3)
+                if (more) dma_part(IntC<2>{}, kt + 2, st_fill);
+                PP_STAMP(1)
+                seg_barrier();
+                PP_STAMP(3)
+                if (more) dma_part(IntC<3>{}, kt + 2, st_fill);
+                PP_STAMP(1)
+                if (more) wait_vmcnt<NP>();  // all but the NP pieces of tile kt+2: tile kt+1 has landed
+                else wait_vmcnt<0>();
+                PP_STAMP(6)
+                seg_barrier();
+                PP_STAMP(3)
+                st_fill = st_fill == NST - 1 ? 0 : st_fill + 1;
+            }
+#ifdef GMD_PP_DIAG
+            diag_end();
+#endif
+            seg_barrier();  // the trailing barrier of the early consumer group
+        }
+        __syncthreads();  // the consumers' barrier in front of their epilogue strips
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumer waves: fragment reads + MFMA
+    const int wr = wid / WN, wc = wid % WN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    uint4 fa[TM], fb[TN];
+    auto frag_reads = [&](int stage_idx, int s2) {
+        const unsigned char* sA = smem + stage_idx * kStage;
+        const unsigned char* sW = sA + BM * 128;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA + lds_off(wr * 64 + i * 16 + frow, 4 * s2 + fq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(sW + lds_off(wc * (TN * 16) + j * 16 + frow, 4 * s2 + fq));
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Half<HT>::mfma16(fb[j], fa[i], acc[i][j]);
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+    if (nk > 0) {  // block-uniform (split-K slices beyond the last K step skip the loop and its barriers together)
+        seg_barrier();                  // #0: tile 0 is in LDS
+        if (late) seg_barrier();        // the stagger
+        int st = 0;
+#ifdef GMD_PP_DIAG
+        diag_begin();
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                frag_reads(st, s2);
+                lgkm0();
+                PP_STAMP(0)
+                seg_barrier();
+                PP_STAMP(3)
+                __builtin_amdgcn_s_setprio(1);
+                mfmas();
+                __builtin_amdgcn_s_setprio(0);
+                PP_STAMP(4)
+                seg_barrier();
+                PP_STAMP(5)
+            }
+            st = st == NST - 1 ? 0 : st + 1;
+        }
+#ifdef GMD_PP_DIAG
+        diag_end();
+#endif
+        if (!late) seg_barrier();
+    }
+    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
+                         (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
+                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    __syncthreads();  // every wave (loaders included) is done with the K-loop stages: the strips below overwrite them
+    if constexpr (TN % 2 == 0) {
+        if (p.act == GMD_ACT_GEGLU && !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+            constexpr int kStripG = 32 * (TN * 8 + 4);
+            epilogue_rows_geglu<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+            return;
+        }
+    }
+    if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+        constexpr int kStripS = 32 * (TN * 16 + 4);
+        epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        return;
+    }
+    if (rows_ok) {
+        constexpr int kStrip = 32 * (TN * 16 + 4);
+        static_assert((size_t)NCONS * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
+        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+    } else {
+        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+    }
+}
+#undef PP_STAMP
+
+// ------------------------------------------------------------------------------------------------
 // float32 FMA kernel (parity path): 64x64x16 tiles, 4x4 outputs per thread
 // ------------------------------------------------------------------------------------------------
 template <bool CONV>
@@ -995,6 +1319,8 @@ struct Force {
     }
 };
 Force g_force;  // read once when the library is loaded
+// GMD_PP=0 keeps the round-3 plans (A/B measurements of whole runs; read once when the library is loaded)
+const bool g_pp_enabled = [] { const char* e = getenv("GMD_PP"); return !(e && e[0] == '0'); }();
 
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
@@ -1038,6 +1364,25 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
         pl.bn = 64;
     }
     if (fks) pl.ksplit = ((int64_t)fks * M * N * (int64_t)sizeof(float) <= ws_bytes && batch == 1) ? fks : 1;
+    // Ping-pong kernel (gemm_pp_kernel, plan code 283): one 256-row workgroup per CU.  Taken where it measured faster than the
+    // plans above on the UNet's / VAE's shapes (tools/sweep_pp.py, device time inside a HIP graph, batch 8 and 4):
+    //   * >= 256 tiles of 256 x 160 (every level-0 linear / convolution at batch 8: +3...+18 %), or of 256 x 128 where N is not a
+    //     multiple of 160 (VAE decoder: +2...+12 %);
+    //   * about half a chip of 256 x 160 tiles with a deep K, as two K slices (conv 32x32 1280->640 / 1920->640 at batch 8, level-0
+    //     960->320 at batch 4: +11...+20 %);
+    //   * the GEGLU projection (256 x 128, value | gate pairs) from K = 1280 up, or K = 640 with at least 8192 rows (+5...+14 %).
+    if (g_pp_enabled && batch == 1 && !(fbm && fbn) && !fpf && !fks && M >= 256) {
+        const int64_t mt = (M + 255) / 256;
+        if (pair_tiles) {
+            if (N % 128 == 0 && ((nk >= 20 && M >= 512) || (nk >= 10 && M >= 8192))) pl = Plan{256, 128, 283, 1};
+        } else if (N % 160 == 0) {
+            const int64_t t160 = mt * (N / 160);
+            if (t160 >= 256) pl = Plan{256, 160, 283, 1};
+            else if (t160 >= 100 && t160 <= 128 && nk >= 120 && 2 * (int64_t)M * N * (int64_t)sizeof(float) <= ws_bytes) pl = Plan{256, 160, 283, 2};
+        } else if (N % 128 == 0 && mt * (N / 128) >= 256) {
+            pl = Plan{256, 128, 283, 1};
+        }
+    }
     return pl;
 }
 
@@ -1066,13 +1411,25 @@ hipError_t launch_ring(const GemmParams& p, int gz, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <typename HT, bool CONV, int TN>
+hipError_t launch_pp(const GemmParams& p, int gz, hipStream_t s) {
+    constexpr int BM = 256, BN = 2 * TN * 16;
+    constexpr size_t smem = (size_t)3 * (BM + BN) * 128;
+    hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_pp_kernel<HT, CONV, TN>), (int)smem);
+    if (e != hipSuccess) return e;
+    dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);
+    gemm_pp_kernel<HT, CONV, TN><<<grid, 768, smem, s>>>(p);
+    return hipGetLastError();
+}
+
 // One 16-bit element type (bf16_t or f16_t): plan, kernel choice, split-K reduction.  float16 instantiates the kernels the
 // heuristic actually picks; the register-staged and deeper-ring tuning variants exist for bfloat16 only (plan overrides).
 // Column statistics (GemmParams::colstats) come out of the row epilogue of the default ring kernels only: every tile must be a
 // full tile of a single, unsplit launch whose waves own 64 rows x (BN/2) columns, a whole number of buckets.
 bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
-    return pl.pf == 0 && pl.bm == 128 && (pl.bn == 160 || pl.bn == 128) && pl.ksplit == 1 && batch == 1 && bucket > 0 &&
-           M % 128 == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0;
+    const bool ring = pl.pf == 0 && pl.bm == 128, pp = pl.pf == 283 && pl.bm == 256;  // both: waves own 64 rows x (BN/2) columns
+    return (ring || pp) && (pl.bn == 160 || pl.bn == 128) && pl.ksplit == 1 && batch == 1 && bucket > 0 &&
+           M % pl.bm == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0;
 }
 
 // The one place that refuses a plan (heuristic or forced) whose kernel lacks an epilogue the launch asks for; nullptr = fine.
@@ -1082,7 +1439,7 @@ bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
 //   * column statistics come out of the full-tile row epilogue of the two default 128-row ring kernels only.
 const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch) {
     if (p.act == GMD_ACT_GEGLU) {
-        const bool odd_tn = pl.bn == 160 || (pl.pf >= 100 && pl.bm == 64 && pl.bn == 64);  // TN = 5 / ring<1,4,1,.>: TN = 1
+        const bool odd_tn = pl.bn == 160 || (pl.pf >= 100 && pl.pf != 283 && pl.bm == 64 && pl.bn == 64);  // TN = 5 / ring<1,4,1,.>: TN = 1
         if (odd_tn || pl.ksplit > 1 || p.out_f32) return "has no GEGLU epilogue";
     }
     if (p.colstats) {
@@ -1108,7 +1465,12 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
     bool done = false;
-    if constexpr (kTune) {
+    if (pl.pf == 283) {  // ping-pong kernel: 8 consumer + 4 loader waves on a 256-row tile
+        if (pl.bm == 256 && pl.bn == 160) e = launch_pp<HT, CONV, 5>(p, gz, s);
+        else if (pl.bm == 256 && pl.bn == 128) e = launch_pp<HT, CONV, 4>(p, gz, s);
+        else { gmd_set_error("%s: ping-pong tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
+        done = true;
+    } else if constexpr (kTune) {
         done = true;
         // pf 1xx selects a ring kernel (experiments): 1WS with W = waves-in-M (2|4), S = stages
         if (pl.pf == 143 && pl.bn == 160) e = launch_ring<HT, CONV, 4, 2, 5, 3>(p, gz, s);
@@ -1131,7 +1493,7 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
         else if (pl.pf != 0 && !(pl.bm == 128))
             e = pl.pf == 1 ? launch_bf16<HT, CONV, 64, 64, 1>(p, gz, s) : launch_bf16<HT, CONV, 64, 64, 2>(p, gz, s);
         else done = false;
-    } else if (pl.pf != 0) {
+    } else if (pl.pf != 0 && pl.pf != 283) {
         gmd_set_error("%s: plan override pf=%d is instantiated for bfloat16 only", name, pl.pf);
         return GMD_ERR_UNSUPPORTED;
     }
@@ -1194,6 +1556,13 @@ int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit) {
 int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket) {
     if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 0;
     return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false), M, N, batch, bucket) ? 1 : 0;
+}
+
+int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4) {
+    GMD_REQUIRE(gmd_is_half(dtype) && M > 0 && N > 0 && K > 0 && K % BK == 0 && batch > 0 && out4, "gmd_gemm_plan_info: 16-bit launches only");
+    const Plan pl = make_plan(M, N, K, batch, workspace_bytes, geglu != 0);
+    out4[0] = pl.bm; out4[1] = pl.bn; out4[2] = pl.pf; out4[3] = pl.ksplit;
+    return GMD_OK;
 }
 
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype, int M, int N, int K, int64_t lda,

@@ -222,6 +222,16 @@ def _colstats_buffer(want, dtype, M, N, K, batch, out_dtype, device):
     return torch.empty((M // 64, N // COLSTATS_BUCKET, 2), dtype=torch.float32, device=device)
 
 
+def gemm_plan_info(dtype, M, N, K, batch=1, geglu=False):
+    """(tile rows, tile columns, kernel code, K slices) a 16-bit gemm_nt / conv3x3 launch of these dimensions takes (conv: M =
+    B*Hout*Wout, N = Cout, K = 9*Cin); kernel code 283 = the ping-pong kernel.  For tests and measurement tools."""
+    import ctypes
+
+    out = (ctypes.c_int * 4)()
+    check(lib().gmd_gemm_plan_info(dtype_code(dtype), M, N, K, batch, WORKSPACE_BYTES, int(geglu), ctypes.addressof(out)), "gmd_gemm_plan_info")
+    return tuple(out)
+
+
 def carry_colstats(dst, src):
     """``dst`` is a view of ``src`` with the same rows x channels content: keep the producer statistics attached."""
     st = getattr(src, "_colstats", None)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 8
+#define GMD_ABI_VERSION 9
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -219,6 +219,13 @@ int gmd_split_weights(const float* W, void* out, int64_t N, int64_t K, int64_t l
  * launch of these dimensions will, 0 otherwise (asking for colstats then fails with GMD_ERR_UNSUPPORTED).  For a
  * convolution pass M = B*Hout*Wout, N = Cout, K = 9*Cin. */
 int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket);
+
+/* Which kernel a 16-bit gmd_gemm_nt / gmd_conv3x3 launch of these dimensions takes (for a convolution M = B*Hout*Wout, N = Cout,
+ * K = 9*Cin; `geglu` = 1 for GMD_ACT_GEGLU launches): out4 = {tile rows, tile columns, kernel code, K slices}.  Kernel codes:
+ * 0 = the LDS-DMA ring kernels (two 4-wave workgroups per CU; 64x64 tiles for under-filled launches), 283 = the ping-pong kernel
+ * (one workgroup of 8 consumer + 4 loader waves on a 256-row tile, round 4).  Pure host function: tests and measurement tools use
+ * it to know what they exercise; nothing in the product path calls it.  Returns GMD_ERR_INVALID for other element types. */
+int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4);
 
 /* GEGLU feed-forward of a BasicTransformerBlock in ONE launch (diffusers FeedForward: ff.net.0 = GEGLU(C -> 4C), ff.net.2 =
  * Linear(4C -> C); the reference reaches it through UNet2DConditionModel at stable_diffusion_dual_unet.py:1052, 1083):

@@ -241,7 +241,10 @@ def test_sd15_unet_bf16_producer_statistics_path_vs_oracle_and_vs_statistics_lau
     before = ops.colstats_uses
     got = hu(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
     used = ops.colstats_uses - before
-    assert used >= 16, used  # every GroupNorm of the 64x64 level (at batch 4 the 32x32 level's launches are too small to emit)
+    # the GroupNorms of the 64x64 level (at batch 4 the 32x32 level's launches are too small to emit); one of the 16 lost its
+    # producer statistics in round 4: the 960->320 convolution at batch 4 runs as two K slices of the ping-pong kernel
+    # (126 -> 105 us, tools/sweep_pp.py) and split-K launches emit none
+    assert used >= 15, used
     ops.USE_COLSTATS = False
     try:
         plain = hu(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]

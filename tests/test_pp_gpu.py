@@ -1,0 +1,200 @@
+"""The ping-pong GEMM kernel (csrc/gemm.hip: gemm_pp_kernel -- one workgroup of 8 consumer + 4 loader waves on a 256-row tile,
+plan code 283) through the C ABI: the shapes the heuristic hands it, and -- through the debug plan override -- the corners of its
+addressing (ragged M / N, stride 2, fused upsample, asymmetric pad, K slices, row bias across a sample seam, both 16-bit types,
+GEGLU pairs, producer column statistics) against float64 references computed by torch on the host."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture
+def force_plan():
+    """gmd_gemm_plan_override is refused unless the process has GMD_TUNING=1 (include/gmd_hip.h)."""
+    from gm_diffusion._native import lib
+
+    prev = os.environ.get("GMD_TUNING")
+    os.environ["GMD_TUNING"] = "1"
+
+    def force(bm, bn, pf, ks):
+        assert lib().gmd_gemm_plan_override(bm, bn, pf, ks) == 0
+
+    yield force
+    lib().gmd_gemm_plan_override(0, 0, 0, 0)
+    if prev is None:
+        os.environ.pop("GMD_TUNING", None)
+    else:
+        os.environ["GMD_TUNING"] = prev
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _conv_ref(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, upsample=False, pad_mode=0):
+    ci, co = x.shape[-1], w.shape[0]
+    xi = x.double().view(B, H, W, ci).permute(0, 3, 1, 2)
+    wt = w.double().view(co, 3, 3, ci).permute(0, 3, 1, 2)
+    if upsample:
+        xi = F.interpolate(xi, scale_factor=2, mode="nearest")
+    if pad_mode == 1:
+        y = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wt, stride=2)
+    else:
+        y = F.conv2d(xi, wt, stride=stride, padding=1)
+    y = y.permute(0, 2, 3, 1).reshape(B, -1, co)
+    if bias is not None:
+        y = y + bias.double()
+    if rowbias is not None:
+        y = y + rowbias.double()[:, None, :]
+    if residual is not None:
+        y = y + residual.double()
+    return y
+
+
+@pytest.mark.parametrize("M,N,K,geglu,expect", [
+    (32768, 320, 320, False, (256, 160, 283, 1)),    # level-0 projections at batch 8
+    (32768, 320, 1280, False, (256, 160, 283, 1)),   # level-0 ff2
+    (8192, 1280, 640, False, (256, 160, 283, 1)),    # level-1 fused qk
+    (8192, 640, 11520, False, (256, 160, 283, 2)),   # conv 32x32 1280->640 at batch 8: two K slices
+    (16384, 320, 8640, False, (256, 160, 283, 2)),   # conv 64x64 960->320 at batch 4
+    (2048, 10240, 1280, True, (256, 128, 283, 1)),   # level-2 GEGLU projection
+    (8192, 5120, 640, True, (256, 128, 283, 1)),
+    (131072, 512, 4608, False, (256, 128, 283, 1)),  # VAE decoder 128x128 512->512 at batch 8
+])
+def test_heuristic_hands_these_launches_to_the_ping_pong_kernel(M, N, K, geglu, expect):
+    from gm_diffusion import hip_ops as ops
+
+    assert ops.gemm_plan_info(torch.bfloat16, M, N, K, 1, geglu) == expect
+
+
+@pytest.mark.parametrize("M,N,K,geglu", [(4096, 640, 640, False), (512, 1280, 1280, False), (16384, 2560, 320, True), (2048, 1280, 5120, False)])
+def test_heuristic_keeps_the_ring_kernels_elsewhere(M, N, K, geglu):
+    from gm_diffusion import hip_ops as ops
+
+    assert ops.gemm_plan_info(torch.bfloat16, M, N, K, 1, geglu)[2] == 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-3), (torch.float16, 5e-4)])
+@pytest.mark.parametrize("M,N,K", [(32768, 320, 320), (8192, 1280, 640), (4096, 320, 1280)])
+def test_pp_gemm_with_bias_and_residual_vs_float64(M, N, K, dtype, tol, force_plan):
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    if ops.gemm_plan_info(dtype, M, N, K)[2] != 283:
+        force_plan(256, 160, 283, 1)
+    y = ops.gemm_nt(a, w, bias=b, residual=r)
+    ref = a.double() @ w.double().T + b.double() + r.double()
+    assert _rel(y, ref) < tol
+
+
+@pytest.mark.parametrize("bn,ks", [(160, 1), (128, 1), (160, 2), (128, 3)])
+def test_pp_ragged_edges_and_k_slices_vs_float64(bn, ks, force_plan):
+    """M and N not multiples of the tile (register epilogue, zero-filled out-of-range rows), K slices with the fixed-order
+    reduction, 5 K steps over 3 slices (the last slice has fewer steps)."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(bn + ks)
+    M, N, K = 1000, 328, 320
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    force_plan(256, bn, 283, ks)
+    y = ops.gemm_nt(a, w, bias=b, act=ops.ACT_SILU)
+    ref = F.silu(a.double() @ w.double().T + b.double())
+    assert y.shape == (M, N) and _rel(y, ref) < 4e-3
+    yf = ops.gemm_nt(a, w, bias=b, out_dtype=torch.float32)  # float32 output straight from the accumulators
+    assert _rel(yf, a.double() @ w.double().T + b.double()) < 1e-5 + (3e-3 if ks > 1 else 0)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stride=2), dict(upsample=True), dict(stride=2, pad_mode=1)])
+@pytest.mark.parametrize("bn", [160, 128])
+def test_pp_conv3x3_variants_vs_float64(kw, bn, force_plan):
+    """Implicit-GEMM addressing of the loader waves: zero padding, stride 2, the VAE's (0,1,0,1) pad, the fused nearest-2x upsample,
+    a per-sample row bias (time embedding) whose sample seam falls inside a 256-row tile, residual; odd feature-map sizes (the
+    division path of the pixel decomposition)."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(bn + len(kw))
+    B, H, W, ci, co = 3, 24, 20, 128, 320
+    x = torch.randn(B, H * W, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.03).bfloat16().to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    tb = torch.randn(B, co, generator=g).to(DEV)
+    force_plan(256, bn, 283, 1)
+    y, ho, wo = ops.conv3x3(x, w, B, H, W, bias=b, rowbias=tb, **kw)
+    ref = _conv_ref(x, w, B, H, W, bias=b, rowbias=tb, **kw)
+    assert y.shape == ref.shape and _rel(y, ref) < 4e-3
+    r = torch.randn(B, ho * wo, co, generator=g).bfloat16().to(DEV)
+    y2, _, _ = ops.conv3x3(x, w, B, H, W, bias=b, residual=r, **kw)
+    assert _rel(y2, _conv_ref(x, w, B, H, W, bias=b, residual=r, **kw)) < 4e-3
+
+
+def test_pp_conv3x3_channel_block_order_and_two_k_slices_equal_unsplit(force_plan):
+    """64x64, Cin = 640: the host picks a channel-block K order (cblk 320); two K slices must give the unsplit result up to the
+    float32 summation order, and both the float64 convolution to bf16 rounding."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(5)
+    B, H, ci, co = 2, 64, 640, 320
+    x = torch.randn(B, H * H, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.02).bfloat16().to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    force_plan(256, 160, 283, 1)
+    y1, _, _ = ops.conv3x3(x, w, B, H, H, bias=b)
+    force_plan(256, 160, 283, 2)
+    y2, _, _ = ops.conv3x3(x, w, B, H, H, bias=b)
+    ref = _conv_ref(x, w, B, H, H, bias=b)
+    assert _rel(y1, ref) < 4e-3 and _rel(y2, ref) < 4e-3
+    assert float((y1.float() - y2.float()).abs().max()) <= 2 * float(ref.abs().max()) * 2 ** -8
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 6e-3), (torch.float16, 8e-4)])
+def test_pp_geglu_epilogue_vs_float64(dtype, tol, force_plan):
+    """value * gelu_erf(gate) on 16-row interleaved [value | gate] weight rows (GMD_ACT_GEGLU), written as [M, N/2]."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(11)
+    M, C = 2048, 320
+    x = torch.randn(M, C, generator=g).to(dtype).to(DEV)
+    w1 = (torch.randn(8 * C, C, generator=g) * 0.05).to(dtype)
+    b1 = torch.randn(8 * C, generator=g) * 0.5
+    half = 4 * C  # [16 value rows | 16 gate rows] groups: the layout of GMD_ACT_GEGLU
+    wi = torch.stack([w1[:half].reshape(half // 16, 16, -1), w1[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1).contiguous().to(DEV)
+    bi = torch.stack([b1[:half].reshape(half // 16, 16), b1[half:].reshape(half // 16, 16)], 1).reshape(2 * half).contiguous().to(DEV)
+    force_plan(256, 128, 283, 1)
+    y = ops.gemm_nt(x, wi, bias=bi, act=ops.ACT_GEGLU)
+    h = x.double().cpu() @ w1.double().T + b1.double()
+    val, gate = h[:, : 4 * C], h[:, 4 * C:]
+    ref = val * F.gelu(gate)
+    assert y.shape == (M, 4 * C) and _rel(y.cpu(), ref) < tol
+
+
+def test_pp_column_statistics_feed_groupnorm(force_plan):
+    """Producer statistics out of the ping-pong kernel's row epilogue (same strips and bucket layout as the ring kernels): sums of
+    the STORED values per 64 rows x 10 channels, and GroupNorm from them == GroupNorm of the stored tensor."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(3)
+    B, H, ci, co = 8, 64, 320, 320
+    x = torch.randn(B, H * H, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.02).bfloat16().to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    assert ops.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)[2] == 283
+    y, _, _ = ops.conv3x3(x, w, B, H, H, bias=b, colstats=True)
+    st, _ = y._colstats
+    yd = y.double().view(B * H * H // 64, 64, co // ops.COLSTATS_BUCKET, ops.COLSTATS_BUCKET)
+    assert float((st[..., 0].double().cpu() - yd.sum((1, 3)).cpu()).abs().max()) < 2e-3
+    assert float(((st[..., 1].double().cpu() - (yd * yd).sum((1, 3)).cpu()).abs() / (yd * yd).sum((1, 3)).cpu()).max()) < 1e-5
+    ga, be = torch.randn(co, generator=g).to(DEV), torch.randn(co, generator=g).to(DEV)
+    a = ops.groupnorm(y, B, 32, ga, be, 1e-5, silu=True)               # consumes the producer statistics
+    y_plain = y.clone()                                                  # no statistics attached: two-launch path
+    bref = ops.groupnorm(y_plain, B, 32, ga, be, 1e-5, silu=True)
+    assert float((a.float() - bref.float()).abs().max()) <= 2 ** -6

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4d; mkdir -p $O
+timeout -k 10 400 python3 $R/tools/check_ring.py 256,160,283,1 256,128,283,1 > $O/check_pp.txt 2>&1
+cat $O/check_pp.txt
+timeout -k 10 300 python3 $R/tools/pp_diag.py 256,160,283,1 > $O/pp_diag.txt 2>&1
+cat $O/pp_diag.txt
