@@ -57,8 +57,10 @@ extern "C" {
 
 int64_t gmd_rgbe_rle_bound(int H, int W) {
     if (H <= 0 || W <= 0) return 0;
-    // per component at most one count byte per 128 literals (+1), runs never expand; 4 header bytes per scanline
-    return (int64_t)H * (4 + 4 * ((int64_t)W + W / 128 + 2));
+    // per component at most one count byte per 128 literals (+1), runs never expand; 4 header bytes per scanline; + W bytes
+    // behind the worst-case output for the encoder's one-plane scratch line (it must never overlap bytes already written:
+    // for a wide, short, incompressible picture -- 1 x 1000 -- the slack of the first term alone is smaller than W)
+    return (int64_t)H * (4 + 4 * ((int64_t)W + W / 128 + 2)) + W;
 }
 
 int gmd_rgbe_rle_encode(const uint8_t* rgbe, int H, int W, uint8_t* out, int64_t capacity, int64_t* out_bytes) {
@@ -79,7 +81,7 @@ int gmd_rgbe_rle_encode(const uint8_t* rgbe, int H, int W, uint8_t* out, int64_t
         return GMD_OK;
     }
     int64_t o = 0;
-    uint8_t* plane = out + capacity - W;  // scratch for one component of one line at the very end of the (bounded) buffer
+    uint8_t* plane = out + capacity - W;  // scratch for one component of one line: the last W bytes, behind the worst-case output
     for (int y = 0; y < H; ++y) {
         const uint8_t* line = rgbe + (int64_t)y * W * 4;
         out[o++] = 2; out[o++] = 2; out[o++] = (uint8_t)(W >> 8); out[o++] = (uint8_t)(W & 0xff);

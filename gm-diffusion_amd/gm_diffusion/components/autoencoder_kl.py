@@ -20,7 +20,7 @@ import torch
 from .. import hip_ops as ops
 from .._native import HipExtensionError
 from .configuration import read_state_dict
-from .unet_2d_condition import _HipModule, _pad_to, composed_attention
+from .unet_2d_condition import _HipModule, _in_own_f32_mode, _pad_to, composed_attention
 
 SD15_VAE_DEFAULTS = dict(
     in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
@@ -233,6 +233,7 @@ class AutoencoderKL(_HipModule):
     # ---- public ------------------------------------------------------------------------------
     max_tensor_bytes = (1 << 32) - 1  # addressable through one raw buffer descriptor
 
+    @_in_own_f32_mode
     def decode_nhwc(self, z):
         """z: float32 NCHW latents (already divided by scaling_factor).  Returns ([B, H*W, 4] float32
         channels-last image, channel 3 is padding), H, W."""
@@ -270,6 +271,7 @@ class AutoencoderKL(_HipModule):
         img = ops.unpack_nchw(y, z.shape[0], self.config.out_channels, H, W)
         return (img,) if not return_dict else SimpleNamespace(sample=img)
 
+    @_in_own_f32_mode
     def encode(self, x, return_dict=True):
         """x: float32 NCHW image in [-1,1] -> latent_dist (generate_hdr.py:208)."""
         self._ensure()

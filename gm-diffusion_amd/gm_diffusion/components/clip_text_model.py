@@ -22,7 +22,7 @@ import torch
 from .. import hip_ops as ops
 from .._native import HipExtensionError
 from .configuration import read_state_dict
-from .unet_2d_condition import _HipModule, composed_attention
+from .unet_2d_condition import _HipModule, _in_own_f32_mode, composed_attention
 
 CLIP_L_TEXT_DEFAULTS = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
                             num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5,
@@ -142,6 +142,7 @@ class CLIPTextModel(_HipModule):
             return ops.attention(qk, qk, vt, H, T, scale, k_col=C, causal=True)
         return composed_attention(qk, 0, 2 * C, qk, C, 2 * C, vt, B, H, d, T, T, scale, self._dtype, causal=True)
 
+    @_in_own_f32_mode
     def __call__(self, input_ids, attention_mask=None, position_ids=None, output_hidden_states=False, return_dict=True):
         self._ensure()
         if attention_mask is not None and not bool(torch.all(attention_mask != 0)):

@@ -60,6 +60,28 @@ def _pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+def _in_own_f32_mode(fn):
+    """Run a module's compute method under the float32 contraction mode its weights were laid out for.  The mode
+    (``hip_ops.F32_MODE``) is a process-wide switch that ``hip_ops`` reads at every call, while a module's weights are pre-split /
+    power-of-two scaled / channel-padded for ONE mode when they are placed on the device: a model prepared under "split" and run
+    after ``set_f32_mode("exact")`` (bench.py holds both kinds alive) would otherwise run the split kernels' weights through the
+    exact kernels or the other way round.  16-bit modules do not depend on the mode."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(self, *args, **kwargs):
+        self._ensure()
+        if self._dtype != torch.float32 or self._f32_mode == ops.F32_MODE:
+            return fn(self, *args, **kwargs)
+        prev = ops.set_f32_mode(self._f32_mode)
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            ops.set_f32_mode(prev)
+
+    return run
+
+
 class _HipModule(ConfigMixin):
     """Shared weight handling: raw CPU float32 state-dict -> device tensors in kernel layouts."""
 
@@ -68,6 +90,7 @@ class _HipModule(ConfigMixin):
         self._w = None         # prepared device tensors
         self._dtype = torch.float32
         self._device = torch.device("cpu")
+        self._f32_mode = None  # float32 contraction mode the prepared weights are laid out for (set by _ensure)
 
     @property
     def dtype(self):
@@ -126,12 +149,13 @@ class _HipModule(ConfigMixin):
             raise HipExtensionError(f"{type(self).__name__} runs on hand-written HIP kernels only; call .to('cuda') "
                                     "(there is no CPU fallback in the MI355X build)")
         ops.dtype_code(self._dtype)
+        self._f32_mode = ops.F32_MODE  # _prepare and every later forward of this module use THIS mode (_in_own_f32_mode)
         self._w = self._prepare()
 
     # -- layout helpers --------------------------------------------------------------------------
     def _kmul(self):
         """Channel multiple the convolution kernels need: 64 (16-bit), 32 (float32 on the matrix cores), 16 (exact float32)."""
-        return 64 if ops.is_half(self._dtype) else (32 if ops.f32_split() else 16)
+        return 64 if ops.is_half(self._dtype) else (32 if self._split_mode() else 16)
 
     def _act(self, t):
         return t.to(self._device, self._dtype).contiguous()
@@ -140,7 +164,8 @@ class _HipModule(ConfigMixin):
         return t.to(self._device, torch.float32).contiguous()
 
     def _split_mode(self):
-        return self._dtype == torch.float32 and ops.f32_split()
+        """float32 module laid out for the matrix-core ("split") kernels: from the record taken when the weights were prepared."""
+        return self._dtype == torch.float32 and (self._f32_mode or ops.F32_MODE) == "split"
 
     def _wt(self, t):
         """A weight that is the W operand of gemm_nt / conv3x3.  float32 on the matrix cores: scaled by a power of two and
@@ -551,6 +576,7 @@ class UNet2DConditionModel(_HipModule):
         ent["ehs"] = ehs  # holding `ehs` keeps its address from being recycled while the key is valid
         return ent["kc"], ent["vt"]
 
+    @_in_own_f32_mode
     def update_context(self, ehs):
         """Prepare the cross-attention K / V^T of every transformer block for these text hidden states (eager,
         in place).  Called once per pipeline call; required before replaying a captured forward."""
@@ -631,6 +657,7 @@ class UNet2DConditionModel(_HipModule):
         cross-attention."""
         return self.config.down_block_types[0].startswith("CrossAttn") and self.config.addition_embed_type is None
 
+    @_in_own_f32_mode
     def set_added_cond(self, added_cond_kwargs, B):
         """SDXL micro-conditioning (diffusers ``get_aug_embed`` for addition_embed_type "text_time"): sinusoid of every scalar of
         ``time_ids`` [B, 6] concatenated behind the pooled text embedding ``text_embeds`` [B, P], through add_embedding.linear_1 ->
@@ -677,6 +704,7 @@ class UNet2DConditionModel(_HipModule):
         ent["src"] = (te, ids)  # keep the sources alive while the key is valid
         return ent["aug"]
 
+    @_in_own_f32_mode
     def forward_packed(self, x, B, H, W, encoder_hidden_states, cfg_shared=False):
         """x: packed channels-last input [B, H*W, cin_pad]; the timestep must already be in ``_t_dev``.
         Returns float32 eps [B, out_channels, H, W].  Stream-ordered, allocation via torch only.
@@ -738,6 +766,7 @@ class UNet2DConditionModel(_HipModule):
         y, _, _ = ops.conv3x3(x, w["conv_out"][0], B, H, W, bias=w["conv_out"][1], out_dtype=torch.float32)
         return ops.unpack_nchw(y, B, c.out_channels, H, W)
 
+    @_in_own_f32_mode
     def graphed_forward(self, B, H, W, ehs, cfg_shared=False):
         """Capture ``forward_packed`` for this (batch, latent size) into a HIP graph (one per shape, cached).
         Returns an object with ``.x`` (static packed-input buffer: fill it with ``pack_input(..., out=g.x)``) and
@@ -771,7 +800,7 @@ class UNet2DConditionModel(_HipModule):
         g.ws = ops.new_workspace(self._device)  # this graph's own split-K scratch (see hip_ops.workspace_scope)
         self._capturing = True
         try:
-            with ops.workspace_scope(g.ws), torch.cuda.graph(g.graph):
+            with ops.capture_in_flight(), ops.workspace_scope(g.ws), torch.cuda.graph(g.graph):
                 g.out = self.forward_packed(g.x, B, H, W, ehs, cfg_shared=cfg_shared)
         finally:
             self._capturing = False
@@ -780,6 +809,7 @@ class UNet2DConditionModel(_HipModule):
         self._graphs[key] = g
         return g
 
+    @_in_own_f32_mode
     def prepare_context(self, encoder_hidden_states):
         """Cast text-encoder hidden states to the UNet dtype once (HIP cast kernel)."""
         self._ensure()
@@ -807,6 +837,7 @@ class UNet2DConditionModel(_HipModule):
             raise ValueError(f"UNet expects {self.config.in_channels} input channels, got {nch}")
         return ops.pack_unet_input(a.contiguous(), None if b is None else b.contiguous(), dup, self._cin_pad, self._dtype, out=out)
 
+    @_in_own_f32_mode
     def __call__(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
                  added_cond_kwargs=None, return_dict=True, **kwargs):
         if timestep_cond is not None:

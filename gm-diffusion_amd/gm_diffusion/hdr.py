@@ -31,6 +31,8 @@ def decode_to_hdr(vae, sdr_latent, gm_latent, qmax=99.0, eps=1 / 64, clamp=False
     # both latents go through the (shared) decoder as ONE batch of 2B: half the launches, fuller grids
     both = torch.cat([_f32(sdr_latent), _f32(gm_latent)], 0)
     dec, H, W = vae.decode_nhwc(ops.tmo(both, 5, mu=inv))  # [2B, H*W, 4] float32
+    if vae.dtype == torch.float32:
+        ops.check_split_range("decode_to_hdr: decoded images", dec, module=vae)  # the VAE's activations are the widest of the path
     return ops.hdr_tail(dec[:B], dec[B:], 2, B, H, W, qmax=qmax, eps=eps, clamp=clamp, want=want)
 
 

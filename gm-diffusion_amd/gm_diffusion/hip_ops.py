@@ -66,6 +66,27 @@ def f32_split():
     return F32_MODE == "split"
 
 
+def check_split_range(what, *tensors, module=None):
+    """Range guard of the float32 "split" path.  Every operand of a split contraction is taken as f16 hi + f16 lo: a value
+    beyond float16's largest finite number (65504) becomes hi = inf, lo = -inf and the product NaN -- the exact float32 kernels
+    have no such limit.  The kernels do not test for it (the split is already the vector-unit bottleneck); the models'
+    consumers -- both pipelines on their final latents, ``hdr.decode_to_hdr`` on the decoded images -- call this once per run
+    on their OUTPUTS (a NaN reaches them through every following layer).  One reduction and one host synchronisation; only for
+    float32 tensors produced under "split".  Raises instead of returning poisoned images."""
+    mode = getattr(module, "_f32_mode", None) or F32_MODE
+    if mode != "split":
+        return
+    for t in tensors:
+        if t is None or not torch.is_tensor(t) or t.dtype != torch.float32 or not t.is_cuda:
+            continue
+        if not bool(torch.isfinite(t).all()):
+            raise HipExtensionError(
+                f"{what}: non-finite values out of the float32 'split' path (matrix cores, three float16 products per float32 "
+                "product).  Its operands must stay inside float16's range: an activation beyond 65504 splits into inf / -inf and "
+                "poisons the product.  Re-run with GMD_F32_MODE=exact (or hip_ops.set_f32_mode('exact') before the models are "
+                "placed on the device): the exact float32 kernels have no range limit.")
+
+
 def split_weights(w):
     """float32 [N, K] (K % 32 == 0) -> the pre-split hi/lo float16 layout of gmd_split_weights, held in a float32 tensor of
     the same shape (same byte count) that is marked ``_split``: gemm_nt / conv3x3 then take it as the GMD_F32SW W operand."""
@@ -616,25 +637,63 @@ def side_stream(device):
 
 
 _SPIN_TICKS = 1_000_000  # ~0.4 ms of torch.cuda._sleep at the MI355X shader clock
+_CAPTURES_IN_FLIGHT = 0  # HIP-graph captures this package has open (components: graphed_forward) -- on ANY stream or thread
+_PROBE_WARNED = False
+
+
+class capture_in_flight:
+    """Marks a HIP-graph capture of this package as open: the side-stream probe synchronises, which would invalidate a capture
+    in progress on another stream, so it does not run while one is open."""
+
+    def __enter__(self):
+        global _CAPTURES_IN_FLIGHT
+        _CAPTURES_IN_FLIGHT += 1
+
+    def __exit__(self, *exc):
+        global _CAPTURES_IN_FLIGHT
+        _CAPTURES_IN_FLIGHT -= 1
+        return False
+
+
+def _probe_note(msg):
+    global _PROBE_WARNED
+    if not _PROBE_WARNED:
+        _PROBE_WARNED = True
+        import warnings
+
+        warnings.warn("gm_diffusion: " + msg + " -- the GM UNet's stream may share the hardware queue of the main stream (the two "
+                      "UNets then run one after the other, ~20 % slower; results are unaffected).  GMD_SIDE_STREAM_SKIP=<n> picks "
+                      "the (n+1)-th new stream without probing.", RuntimeWarning, stacklevel=3)
 
 
 def _stream_beside_current(device, candidates=8):
     """A new stream that really runs BESIDE the current one.  Of the streams a process creates, about every fourth lands on the
     hardware queue of the null stream (tools/stream_queue_probe.py: pool streams 6, 10, 14, ... of a fresh process), so the
     first candidate is not taken on trust: one single-thread spinning kernel on each of the two streams must take the time of one
-    spin, not of two.  ~3 ms, once per device and process; falls back to the first candidate when the probe cannot run."""
+    spin, not of two.  ~3 ms, once per device and process.  The probe is wall-clock based, so it is an optimisation with escape
+    hatches, never a reason to fail: it does not run while a graph capture is open (its synchronisation would invalidate the
+    capture) or when GMD_SIDE_STREAM_SKIP=<n> names the stream to take (the (n+1)-th created here; a host that knows its queue
+    layout, or a shared / busy GPU where timing is noise); when no candidate passes -- or the probe cannot run -- the first
+    candidate is used and ONE RuntimeWarning says so."""
+    skip = os.environ.get("GMD_SIDE_STREAM_SKIP")
+    if skip is not None:
+        junk = [torch.cuda.Stream(device=device) for _ in range(max(0, int(skip)))]
+        st = torch.cuda.Stream(device=device)
+        del junk
+        return st
     first = torch.cuda.Stream(device=device)
     try:
         with torch.cuda.device(device):
-            if torch.cuda.is_current_stream_capturing():
+            if _CAPTURES_IN_FLIGHT > 0 or torch.cuda.is_current_stream_capturing():
+                _probe_note("side-stream probe skipped (a HIP-graph capture is in progress)")
                 return first
             cur = torch.cuda.current_stream()
 
-            def wall(fn):
-                torch.cuda.synchronize()
+            def wall(fn, st):
+                cur.synchronize(); st.synchronize()  # the two streams of the probe only: no device-wide synchronisation
                 t0 = time.perf_counter()
                 fn()
-                torch.cuda.synchronize()
+                cur.synchronize(); st.synchronize()
                 return time.perf_counter() - t0
 
             def both(st):
@@ -643,16 +702,16 @@ def _stream_beside_current(device, candidates=8):
                 torch.cuda._sleep(_SPIN_TICKS)
 
             torch.cuda._sleep(_SPIN_TICKS)
-            one = min(wall(lambda: torch.cuda._sleep(_SPIN_TICKS)) for _ in range(2))
+            one = min(wall(lambda: torch.cuda._sleep(_SPIN_TICKS), first) for _ in range(2))
             st = first
             for _ in range(candidates):
                 both(st)
-                if min(wall(lambda: both(st)) for _ in range(2)) < 1.5 * one:
+                if min(wall(lambda: both(st), st) for _ in range(2)) < 1.5 * one:
                     return st
                 st = torch.cuda.Stream(device=device)
-            del cur
-    except Exception:  # pragma: no cover -- the probe is an optimisation, never a reason to fail
-        pass
+            _probe_note(f"none of {candidates} candidate streams ran beside the current stream in the probe (busy or shared GPU?)")
+    except Exception as e:  # pragma: no cover -- the probe is an optimisation, never a reason to fail
+        _probe_note(f"side-stream probe failed ({e!r})")
     return first
 
 

@@ -252,11 +252,14 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
         if fused:
             sdr_stream.wait_stream(gm_stream)  # join: the caller sees both results on its own stream
             gm_latents.record_stream(sdr_stream)
+        self._check_f32_range("StableDiffusionDualUNetPipeline latents", self.unet, latents)
+        self._check_f32_range("StableDiffusionDualUNetPipeline GM latents", self.gm_unet, gm_latents)
         if output_type == "latent":
             return (latents, gm_latents)
         sf = self.vae.config.scaling_factor
         sdr_image = self.vae.decode(latents / sf, return_dict=False, generator=generator)[0]
         gm_image = self.vae.decode(gm_latents / sf, return_dict=False, generator=generator)[0]
+        self._check_f32_range("StableDiffusionDualUNetPipeline decoded images", self.vae, sdr_image, gm_image)
         do_denormalize = [True] * sdr_image.shape[0]
         sdr_out = self.image_processor.postprocess(sdr_image, output_type=output_type, do_denormalize=do_denormalize)
         gm_out = self.image_processor.postprocess(gm_image, output_type=output_type, do_denormalize=do_denormalize)

@@ -313,6 +313,14 @@ class _GMPipelineBase(DiffusionPipeline):
         return self._interrupt
 
     # ---- shared pieces of __call__ -------------------------------------------------------------
+    @staticmethod
+    def _check_f32_range(what, module, *tensors):
+        """Range guard of the float32 matrix-core path (hip_ops.check_split_range): HIP float32 modules only."""
+        if getattr(module, "dtype", None) == torch.float32 and hasattr(module, "_f32_mode"):
+            from .. import hip_ops as ops
+
+            ops.check_split_range(what, *tensors, module=module)
+
     def _latent_dtype(self, prompt_embeds, device):
         """Latents, scheduler state, CFG and x0 stay float32 on the HIP path (the documented cast point of the
         bf16 configuration: the UNet casts while packing its input); host tensors keep the reference's choice."""
@@ -533,8 +541,10 @@ class StableDiffusionGMPipeline(_GMPipelineBase):
                         step_idx = i // getattr(self.scheduler, "order", 1)
                         callback(step_idx, t, latents)
 
+        self._check_f32_range("StableDiffusionGMPipeline latents", self.unet, latents)
         if not output_type == "latent":
             image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False, generator=generator)[0]
+            self._check_f32_range("StableDiffusionGMPipeline decoded image", self.vae, image)
             image, has_nsfw_concept = self.run_safety_checker(image, device, prompt_embeds.dtype)
         else:
             image = latents

@@ -38,3 +38,21 @@ def test_single_rank_rccl_run_equals_plain_run(extra):
     assert plain["config"]["rccl_world_size"] is None and sharded["config"]["rccl_world_size"] == 1
     assert plain["outputs_finite"] and sharded["outputs_finite"]
     assert plain["output_sha256"] == sharded["output_sha256"]
+
+
+def test_single_rank_rccl_run_at_sd15_width_equals_plain_run():
+    """The SD-1.5-width models through the RCCL leg once on hardware (round-3 review: the group had only ever seen the tiny UNets):
+    full-width synthetic weights, init_process_group("nccl"), the bf16 hidden-state broadcast at cross-attention width 768, the
+    float32 latent broadcast, barrier and max-reduce; 256x256, batch 2, 2 PNDM steps -> HDR codes bit-identical to the plain run."""
+    args = ["--unet", "sd15", "--res", "256", "--batch", "2", "--inference-steps", "2", "--steps", "1", "--warmup", "0", "--dtype", "bf16",
+            "--no-cpu-baseline", "--no-kernel-timing", "--no-drift", "--no-tolerance-path", "--checksum"]
+    plain = _run({}, args)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    sharded = _run({"GMD_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port)}, args)
+    assert "SD-v1-5" in sharded["config"]["workload"] and sharded["config"]["per_gpu_batch"] == 2
+    assert plain["config"]["rccl_world_size"] is None and sharded["config"]["rccl_world_size"] == 1
+    assert plain["outputs_finite"] and sharded["outputs_finite"]
+    assert plain["output_sha256"] == sharded["output_sha256"]

@@ -123,6 +123,15 @@ def test_host_rgbe_run_length_encoder_equals_oracle():
         if h:
             assert np.array_equal(H.rgbe_rle_decode(got, h, w), px)
     assert hdr.rgbe_scanlines(px, "none") == px.tobytes()
+    # wide, short, incompressible: the encoder's one-line scratch sits in the last W bytes of the bounded buffer and must stay
+    # clear of the output (round 3's bound left 4*H + a few bytes of slack: for 1 x 1000 the last planes' literals overlapped it)
+    for h, w in ((1, 1000), (2, 4096), (1, 32767)):
+        px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        px[:, 1:, :] += (px[:, 1:, :] == px[:, :-1, :]).astype(np.uint8)  # no two equal neighbours: literals only, the longest output
+        got = hdr.rgbe_scanlines(px)
+        assert len(got) == h * (4 + 4 * (w + (w + 127) // 128)) and len(got) + w <= lib().gmd_rgbe_rle_bound(h, w)
+        assert got == H.rgbe_rle_scanlines(px), (h, w)
+        assert np.array_equal(H.rgbe_rle_decode(got, h, w), px)
     px = np.zeros((2, 16, 4), np.uint8)
     out = np.zeros(8, np.uint8)
     n = ctypes.c_int64(0)

@@ -95,7 +95,8 @@ def test_dual_pipeline_sd15_width_512_f32_matches_oracle_fixture(sd15, mode):
     assert d_sdr <= RMS_TOL and d_gm <= RMS_TOL
 
 
-@pytest.mark.parametrize("dtype,tol_sdr,tol_gm", [(torch.float16, 3.0e-2, 1.5e-2), (torch.bfloat16, 0.25, 0.12)])
+# measured on MI355X (round 4, 50 steps, vs the CPU oracle): float16 8.7e-3 / 4.5e-3, bfloat16 7.1e-2 / 3.6e-2 -> gates at 2x
+@pytest.mark.parametrize("dtype,tol_sdr,tol_gm", [(torch.float16, 1.8e-2, 9.0e-3), (torch.bfloat16, 0.143, 0.073)])
 def test_dual_pipeline_sd15_width_512_16bit_drift_vs_oracle_fixture(sd15, dtype, tol_sdr, tol_gm):
     """The benchmarked precision (bf16) and float16 on the SAME inputs against the SAME oracle outputs: their drift is a
     reported number (bench.py prints it against the float32 HIP path; here it is against the CPU oracle) and is gated at about

@@ -204,8 +204,23 @@ def test_side_stream_is_chosen_by_a_concurrency_probe():
             both()
             one = min(wall(lambda: torch.cuda._sleep(2_000_000)) for _ in range(3))
             two = min(wall(both) for _ in range(3))
-            assert two < 1.5 * one, f"side stream after {n_before} other streams is serialised with the current stream ({two / one:.2f}x)"
+            # wall-clock ratio: two spins beside each other take ~1.0x one spin, one after the other ~2.0x.  1.7 leaves room for a
+            # noisy host without letting a serialised stream (2.0x) through
+            assert two < 1.7 * one, f"side stream after {n_before} other streams is serialised with the current stream ({two / one:.2f}x)"
             del junk
+        # escape hatch: GMD_SIDE_STREAM_SKIP=<n> takes the (n+1)-th new stream without probing
+        os.environ["GMD_SIDE_STREAM_SKIP"] = "1"
+        try:
+            ops._SIDE_STREAMS.clear()
+            s2 = ops.side_stream(DEV)
+            assert s2 is ops.side_stream(DEV) and s2 != torch.cuda.current_stream()
+        finally:
+            os.environ.pop("GMD_SIDE_STREAM_SKIP", None)
+        # and the probe does not run (no synchronisation) while one of the package's graph captures is open
+        with ops.capture_in_flight(), pytest.warns(RuntimeWarning, match="capture is in progress"):
+            ops._PROBE_WARNED = False
+            ops._SIDE_STREAMS.clear()
+            assert ops.side_stream(DEV) is not None
     finally:
         ops._SIDE_STREAMS.clear()
         ops._SIDE_STREAMS.update(saved)

@@ -369,3 +369,101 @@ def test_new_lds_dma_kernels_are_repeatable_beside_another_stream():
             differ += int(not torch.equal(fn(), first))
         torch.cuda.synchronize()
         assert differ == 0, name
+
+
+def test_split_range_limit_is_guarded_and_the_exact_mode_has_none():
+    """The float32 "split" path takes every operand as f16 hi + f16 lo: an activation beyond 65504 splits into inf / -inf and the
+    product is NaN.  The kernels do not test for it; the consumers of the models' outputs do (hip_ops.check_split_range, called by
+    both pipelines and decode_to_hdr): it must raise a HipExtensionError that names the remedy, and the exact kernels must give
+    the finite result on the same operands."""
+    from gm_diffusion._native import HipExtensionError
+
+    o = ops()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(256, 64, generator=g)
+    x[3, 5] = 1.0e5  # beyond float16's largest finite value
+    w = torch.randn(128, 64, generator=g) * 0.05
+    prev = o.set_f32_mode("split")
+    try:
+        y = o.gemm_nt(x.to(DEV), o.split_weights(w.to(DEV)))
+        assert not torch.isfinite(y[3]).all()          # the documented limit of the split path ...
+        assert torch.isfinite(y[:3]).all() and torch.isfinite(y[4:]).all()  # ... confined to the row that holds the value
+        with pytest.raises(HipExtensionError, match="GMD_F32_MODE=exact"):
+            o.check_split_range("gemm_nt output", y)
+        o.check_split_range("finite rows", y[4:].contiguous())  # no error
+        o.set_f32_mode("exact")
+        ye = o.gemm_nt(x.to(DEV), w.to(DEV))
+        assert torch.isfinite(ye).all() and rel_err(ye, x.double() @ w.double().t()) < 1e-5
+        o.check_split_range("exact output", ye)
+    finally:
+        o.set_f32_mode(prev)
+
+
+def test_pipeline_raises_on_split_range_overflow_and_runs_in_exact_mode():
+    """Same limit end to end: latents of magnitude 1e6 overflow float16 in conv_in's operand split.  The dual pipeline must raise
+    (not return NaN latents) under "split"; placed on the device under "exact" the same call is finite."""
+    from gm_diffusion._native import HipExtensionError
+    from gm_diffusion.components import AutoencoderKL, PNDMScheduler, UNet2DConditionModel
+    from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
+    from oracle import fixtures
+
+    o = ops()
+
+    def pipe():
+        def hip(cls, om):
+            m = cls(**vars(om.config))
+            m.load_state_dict(om.state_dict())
+            return m.to(DEV, torch.float32)
+
+        p = StableDiffusionDualUNetPipeline(
+            vae=hip(AutoencoderKL, fixtures.build_vae("tiny")), text_encoder=None, tokenizer=None,
+            unet=hip(UNet2DConditionModel, fixtures.build_unet("tiny", 4)), gm_unet=hip(UNet2DConditionModel, fixtures.build_unet("tiny", 8)),
+            scheduler=PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1,
+                                    set_alpha_to_one=False), safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+        p.set_progress_bar_config(disable=True)
+        return p
+
+    g = torch.Generator().manual_seed(4)
+    pe, ne = torch.randn(1, 77, 64, generator=g).to(DEV), torch.randn(1, 77, 64, generator=g).to(DEV)
+    lat = (torch.randn(1, 4, 16, 16, generator=g) * 1.0e6).to(DEV)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=128, width=128, num_inference_steps=2, output_type="latent")
+    prev = o.set_f32_mode("split")
+    try:
+        with pytest.raises(HipExtensionError, match="float16's range"):
+            pipe()(**kw)
+        o.set_f32_mode("exact")
+        sdr, gm = pipe()(**kw)
+        assert torch.isfinite(sdr).all() and torch.isfinite(gm).all()
+    finally:
+        o.set_f32_mode(prev)
+
+
+def test_module_keeps_the_f32_mode_it_was_prepared_for():
+    """hip_ops.F32_MODE is a process-wide switch, a module's weights are laid out (pre-split, power-of-two scaled, channel padded)
+    for ONE mode when they reach the device.  A model prepared under one mode must give bit-identical results after the switch
+    was flipped (bench.py keeps split and exact pipelines alive side by side) -- not fail, and not run one mode's weights through
+    the other mode's kernels."""
+    from gm_diffusion.components import AutoencoderKL, UNet2DConditionModel
+    from oracle import fixtures
+
+    o = ops()
+    ou, ov = fixtures.build_unet("tiny", 4), fixtures.build_vae("tiny")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 4, 16, 16, generator=g).to(DEV)
+    ctx = torch.randn(2, 77, ou.config.cross_attention_dim, generator=g).to(DEV)
+    z = torch.randn(2, 4, 8, 8, generator=g).to(DEV)
+    for own, other in (("split", "exact"), ("exact", "split")):
+        prev = o.set_f32_mode(own)
+        try:
+            hu = UNet2DConditionModel(**vars(ou.config)); hu.load_state_dict(ou.state_dict()); hu = hu.to(DEV, torch.float32)
+            hv = AutoencoderKL(**vars(ov.config)); hv.load_state_dict(ov.state_dict()); hv = hv.to(DEV, torch.float32)
+            a = hu(x, 301, encoder_hidden_states=ctx, return_dict=False)[0]
+            da = hv.decode(z, return_dict=False)[0]
+            assert hu._f32_mode == own and hv._f32_mode == own
+            o.set_f32_mode(other)
+            b = hu(x, 301, encoder_hidden_states=ctx, return_dict=False)[0]
+            db = hv.decode(z, return_dict=False)[0]
+            assert o.F32_MODE == other  # the scope restores the caller's mode
+            assert torch.equal(a, b) and torch.equal(da, db), own
+        finally:
+            o.set_f32_mode(prev)
