@@ -1210,6 +1210,261 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
 #undef PP_STAMP
 
 // ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, loader / consumer form (round 4) for launches that have about ONE tile per CU (256 tiles of 128 x 160 or
+// 64 x 160: the transformer linears and the convolutions of the 32x32 / 16x16 levels).  One workgroup of 4 consumer waves (2 x 2,
+// one per SIMD, wave tile 16 TM x 16 TN) + 4 loader waves, a 4-stage LDS ring, ONE barrier per 64-deep K step.
+//
+// Why: such launches run the ring kernel with a single 4-wave workgroup per CU, where every wave serialises its own blocked
+// LDS-DMA issue (~90 cycles per piece while the CU's memory queue is full), its fragment reads and its MFMAs -- the vendor
+// library's kernels for exactly these shapes (profiles/r04_library_tensile_kernels.txt: MT160x128x64, MT160x64x64, MT96x64x64 ...,
+// one wave per SIMD, 256 workgroups) are 7-20 % faster.  Here the loaders own the DMA (blocking costs the consumers nothing) and
+// a consumer issues the fragment reads of the NEXT 32-deep half step (second register set) in front of the MFMAs of the current
+// one, so its matrix pipe never waits for LDS.  These tiles are bound by what a CU can pull from L2 (36 KB per K step at
+// ~36 B/clk = 1000 cycles against 640 MFMA cycles): the loaders are the critical path, the consumers have slack.
+//
+//   consumer:  B(0) ; reads (0, half 0) -> set 0 ;  per K step kt: { reads (kt, 1) -> set 1 ; MFMAs set 0 ;
+//                                                                     reads (kt+1, 0) -> set 0 ; MFMAs set 1 ; B(kt+1) }
+//   loader:    tiles 0..3 ; vmcnt(tiles 0, 1 landed) ; B(0) ;  per kt: { vmcnt(tile kt+2 landed) ; B(kt+1) ; issue tile kt+4 }
+//
+// LDS hazards: B(j) is passed by a loader only after ITS pieces of tile j+1 have landed (counted vmcnt), so every read of tile
+// j+1 -- the first is issued in K step j, behind B(j) -- finds it.  The reads of tile kt are issued in K steps kt-1 and kt and
+// have RETURNED when the MFMAs that consume them were issued, i.e. before B(kt+1); tile kt+4 is written into that stage behind
+// B(kt+1).  Reads still in flight at a barrier target the NEXT tile's stage, which is not rewritten for three more K steps.
+// ------------------------------------------------------------------------------------------------
+template <typename HT, bool CONV, int TM, int TN>
+__global__ __launch_bounds__(512, 2) void gemm_lc_kernel(const GemmParams p) {
+    constexpr int WN = 2, NCONS = 4, LW = 4, NST = 4;
+    constexpr int BM = 2 * TM * 16, BN = WN * TN * 16;
+    constexpr int RPP = LW * 8;                     // 32 tile rows per staging pass
+    constexpr int NA = BM / RPP, NW = BN / RPP, NP = NA + NW;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be whole staging passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kStage = (BM + BN) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+    const bool loader = wuni >= NCONS;
+    int m0, n0;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+        if (p.M >= p.N) {  // n-fastest: an XCD's run of tiles shares its A row panels
+            const int mt = L / tiles_n;
+            m0 = mt * BM;
+            n0 = (L - mt * tiles_n) * BN;
+        } else {           // small-M launches: the weight panel is the larger operand
+            const int nt = L / tiles_m;
+            n0 = nt * BN;
+            m0 = (L - nt * tiles_m) * BM;
+        }
+    }
+    const int z = p.ksplit > 1 ? 0 : blockIdx.z;
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    const int nk_total = p.K / BK;
+    const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * per;
+    const int nk = (kt_begin + per <= nk_total ? per : nk_total - kt_begin);
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (loader) {
+        const int lw = wuni - NCONS;
+        const int ltid = tid - NCONS * 64;
+        const int srow = ltid >> 3;
+        const int chunk = (ltid & 7) ^ ((srow >> 1) & 7);
+        unsigned aoff[NA], woff[NW];
+        int pb[NA], py[NA], px[NA];
+        bool pv[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + srow + RPP * i;
+            pv[i] = m < p.M;
+            pb[i] = py[i] = px[i] = 0;
+            if (CONV) {
+                if (pv[i]) {
+                    const int hw = p.Hout * p.Wout;
+                    if (((hw & (hw - 1)) | (p.Wout & (p.Wout - 1))) == 0) {
+                        const int sh = __builtin_ctz(hw), sw = __builtin_ctz(p.Wout);
+                        pb[i] = m >> sh;
+                        const int rem = m & (hw - 1);
+                        py[i] = rem >> sw;
+                        px[i] = rem & (p.Wout - 1);
+                    } else {
+                        pb[i] = m / hw;
+                        const int rem = m - pb[i] * hw;
+                        py[i] = rem / p.Wout;
+                        px[i] = rem - py[i] * p.Wout;
+                    }
+                }
+                aoff[i] = kOOB;
+            } else {
+                aoff[i] = pv[i] ? (unsigned)m * (unsigned)p.lda * 2u + (unsigned)chunk * 16u : kOOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = n0 + srow + RPP * i;
+            woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u + (unsigned)chunk * 16u : kOOB;
+        }
+        int tap = 0, c0 = 0, cb0 = 0;
+        bool newtap = true;
+        if (CONV) {
+            const int sb = p.cblk / BK, per_cb = 9 * sb;
+            const int cbi = kt_begin / per_cb, rem = kt_begin - cbi * per_cb;
+            tap = rem / sb;
+            cb0 = cbi * p.cblk;
+            c0 = cb0 + (rem - tap * sb) * BK;
+        }
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+        u32x4 dA, dW;
+        {
+            const uint64_t ba = (uint64_t)((const bf16_t*)p.A + (int64_t)z * p.sA), bw = (uint64_t)((const bf16_t*)p.W + (int64_t)z * p.sW);
+            dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+            dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+        }
+        auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                         :
+                         : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                         : "memory", "m0");
+#pragma clang diagnostic pop
+        };
+        auto dma_tile = [&](int kt, int stage_idx) {
+            unsigned kbytes = (unsigned)(kt_begin + kt) * (BK * 2);
+            unsigned abytes = kbytes;
+            if (CONV) {
+                if (newtap) {
+                    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) aoff[i] = conv_tap_offset<CONV>(p, pv[i], pb[i], py[i], px[i], ky, kx, chunk);
+                    newtap = false;
+                }
+                abytes = (unsigned)c0 * 2u;
+                kbytes = (unsigned)(tap * p.Cin + c0) * 2u;
+            }
+            const unsigned stage = lds_base + (unsigned)stage_idx * kStage + (unsigned)lw * (8 * 128);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) dma16(dA, stage + i * (RPP * 128), aoff[i], abytes);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) dma16(dW, stage + BM * 128 + i * (RPP * 128), woff[i], kbytes);
+            if (CONV) {
+                c0 += BK;
+                if (c0 >= cb0 + p.cblk) {
+                    c0 = cb0;
+                    ++tap;
+                    newtap = true;
+                    if (tap == 9) { tap = 0; cb0 += p.cblk; c0 = cb0; }
+                }
+            }
+        };
+        if (nk > 0) {  // block-uniform
+#pragma unroll
+            for (int t = 0; t < NST; ++t)
+                if (t < nk) dma_tile(t, t);
+            // tiles 0 and 1 have landed: at most the pieces of tiles 2 and 3 may remain
+            if (nk >= 4) wait_vmcnt<2 * NP>();
+            else if (nk == 3) wait_vmcnt<NP>();
+            else wait_vmcnt<0>();
+            seg_barrier();  // B(0)
+            int st_fill = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                // tile kt+2 has landed: only tile kt+3 (issued behind B(kt)) may remain -- where it exists
+                if (kt + 3 < nk) wait_vmcnt<NP>();
+                else wait_vmcnt<0>();
+                seg_barrier();  // B(kt+1): publishes tile kt+2, frees the stage of tile kt
+                if (kt + NST < nk) dma_tile(kt + NST, st_fill);
+                st_fill = st_fill == NST - 1 ? 0 : st_fill + 1;
+            }
+        }
+        __syncthreads();  // the consumers' barrier in front of their epilogue strips
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumer waves
+    const int wr = wid / WN, wc = wid % WN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto frag_reads = [&](int stage_idx, int s2, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
+        const unsigned char* sA = smem + stage_idx * kStage;
+        const unsigned char* sW = sA + BM * 128;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA + lds_off(wr * (TM * 16) + i * 16 + frow, 4 * s2 + fq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(sW + lds_off(wc * (TN * 16) + j * 16 + frow, 4 * s2 + fq));
+    };
+    auto mfmas = [&](const uint4 (&fa)[TM], const uint4 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Half<HT>::mfma16(fb[j], fa[i], acc[i][j]);
+    };
+    if (nk > 0) {
+        seg_barrier();  // B(0): tiles 0 and 1 are in LDS
+        frag_reads(0, 0, fa0, fb0);
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int st_next = st == NST - 1 ? 0 : st + 1;
+            frag_reads(st, 1, fa1, fb1);
+            mfmas(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the half steps apart: set 0 is rewritten below
+            // tile kt+1: published by B(kt).  Unconditional -- behind the last K step it reads a stale stage into registers nobody
+            // uses: a branch here makes hipcc wait lgkmcnt(0) in front of the MFMAs above instead of counting the reads
+            frag_reads(st_next, 0, fa0, fb0);
+            mfmas(fa1, fb1);
+            seg_barrier();  // B(kt+1)
+            st = st_next;
+        }
+        // keep the last (unused) prefetch alive: otherwise hipcc sinks it under "is there a next K step", and that branch
+        // turns the counted lgkmcnt in front of the first MFMA block into lgkmcnt(0)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fa0[i])));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb0[j])));
+    }
+    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
+                         (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
+                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    __syncthreads();  // every wave (loaders included) is done with the K-loop stages: the strips below overwrite them
+    if constexpr (TM == 4 && TN % 2 == 0) {
+        if (p.act == GMD_ACT_GEGLU && !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+            constexpr int kStripG = 32 * (TN * 8 + 4);
+            epilogue_rows_geglu<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, z);
+            return;
+        }
+    }
+    if constexpr (TM == 4) {
+        if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+            constexpr int kStripS = 32 * (TN * 16 + 4);
+            epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, ks);
+            return;
+        }
+    }
+    if (rows_ok) {
+        constexpr int kStrip = 32 * (TN * 16 + 4);
+        static_assert((size_t)NCONS * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
+        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, z);
+    } else {
+        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), frow, fq, z, ks);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // float32 FMA kernel (parity path): 64x64x16 tiles, 4x4 outputs per thread
 // ------------------------------------------------------------------------------------------------
 template <bool CONV>
@@ -1288,8 +1543,14 @@ struct Plan {
 // profiles/r01_pmc_conv_attention_current.txt).  Blocks of `cblk` channels bring the distance back under 3 MB
 // (rocprofv3 after: 1.97x, 125.5 -> 118.8 us; profiles/r02_pmc_conv_gemm_traffic.txt).  Shapes whose rows already fit keep
 // the tap-major order (cblk == Cin): at 2.6 MB (32x32, Cin 1280) the blocked order measured slower, not faster.
+bool tuning_enabled();
 int conv_channel_block(int B, int Hin, int Win, int Cin, int Cout, int dtype) {
     if (dtype == GMD_F32) return Cin;
+    if (tuning_enabled()) {  // experiments only (GMD_TUNING=1): GMD_CONV_CBLK=<multiple of 64 dividing Cin>
+        const char* e = getenv("GMD_CONV_CBLK");
+        const int v = e ? atoi(e) : 0;
+        if (v >= 64 && v % 64 == 0 && Cin % v == 0) return v;
+    }
     const int64_t rows_total = (int64_t)B * Hin * Win;
     const int tiles_n = (Cout + 159) / 160;
     const int64_t rows_resident = (int64_t)(64 / tiles_n > 0 ? 64 / tiles_n : 1) * 128;  // input rows under one XCD's resident tiles
@@ -1321,6 +1582,13 @@ struct Force {
 Force g_force;  // read once when the library is loaded
 // GMD_PP=0 keeps the round-3 plans (A/B measurements of whole runs; read once when the library is loaded)
 const bool g_pp_enabled = [] { const char* e = getenv("GMD_PP"); return !(e && e[0] == '0'); }();
+// A/B only: GMD_PP=p keeps the ping-pong kernel alone, GMD_PP=l the loader / consumer kernel alone
+const bool g_pp_only = [] { const char* e = getenv("GMD_PP"); return e && e[0] == 'p'; }();
+const bool g_lc_only = [] { const char* e = getenv("GMD_PP"); return e && e[0] == 'l'; }();
+// A/B only: GMD_PP=b takes the 256-row ping-pong tile with K slices wherever the loader / consumer kernel would be taken
+// (least L2 -> LDS bytes per product: is the two-stream pipeline bound by what the CUs can ingest?)
+const bool g_big_tiles = [] { const char* e = getenv("GMD_PP"); return e && e[0] == 'b'; }();
+const int g_big_variant = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b' && e[1]) ? e[1] - '0' : 0; }();  // b1, b2, ...
 
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
@@ -1364,23 +1632,50 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
         pl.bn = 64;
     }
     if (fks) pl.ksplit = ((int64_t)fks * M * N * (int64_t)sizeof(float) <= ws_bytes && batch == 1) ? fks : 1;
-    // Ping-pong kernel (gemm_pp_kernel, plan code 283): one 256-row workgroup per CU.  Taken where it measured faster than the
-    // plans above on the UNet's / VAE's shapes (tools/sweep_pp.py, device time inside a HIP graph, batch 8 and 4):
-    //   * >= 256 tiles of 256 x 160 (every level-0 linear / convolution at batch 8: +3...+18 %), or of 256 x 128 where N is not a
-    //     multiple of 160 (VAE decoder: +2...+12 %);
-    //   * about half a chip of 256 x 160 tiles with a deep K, as two K slices (conv 32x32 1280->640 / 1920->640 at batch 8, level-0
-    //     960->320 at batch 4: +11...+20 %);
-    //   * the GEGLU projection (256 x 128, value | gate pairs) from K = 1280 up, or K = 640 with at least 8192 rows (+5...+14 %).
-    if (g_pp_enabled && batch == 1 && !(fbm && fbn) && !fpf && !fks && M >= 256) {
-        const int64_t mt = (M + 255) / 256;
+    // Round-4 kernels: one workgroup per CU with dedicated LDS-DMA loader waves.  Taken where they measured faster than the plans
+    // above on the UNet's / VAE's shapes (tools/sweep_pp.py, tools/check_ring.py: device time, batch 8 and 4):
+    //   * ping-pong kernel (gemm_pp_kernel, code 283), 256-row tiles: >= 256 tiles of 256 x 160 (every level-0 linear / convolution
+    //     at batch 8: +3...+18 %), or of 256 x 128 where N is not a multiple of 160 (VAE decoder: +2...+12 %); the GEGLU projection
+    //     (256 x 128, value | gate pairs) from K = 1280 up, or K = 640 with at least 8192 rows (+5...+14 %);
+    //   * loader / consumer kernel (gemm_lc_kernel, code 244), 128- or 64-row tiles, for launches that have about ONE tile per CU
+    //     (200...256 tiles; with K slices where K is deep): conv 32x32 640->640 at batch 8 72.8 -> 55.5 us, 64x64 320->320 at batch 4
+    //     41.3 -> 33.0 us, linear M=2048 N=1280 K=5120 49.4 -> 36.8 us.  More than 256 such tiles would run in two rounds of one
+    //     workgroup per CU (M=8192 N=1280 K=640: 36.5 us against 24.8 us), fewer than ~200 leave CUs idle: both keep the plans above.
+    if (g_pp_enabled && batch == 1 && !(fbm && fbn) && !fpf && !fks && M >= 64) {
+        const int64_t mt256 = (M + 255) / 256;
+        const int bn = N % 160 == 0 ? 160 : (N % 128 == 0 ? 128 : 0);
         if (pair_tiles) {
-            if (N % 128 == 0 && ((nk >= 20 && M >= 512) || (nk >= 10 && M >= 8192))) pl = Plan{256, 128, 283, 1};
-        } else if (N % 160 == 0) {
-            const int64_t t160 = mt * (N / 160);
-            if (t160 >= 256) pl = Plan{256, 160, 283, 1};
-            else if (t160 >= 100 && t160 <= 128 && nk >= 120 && 2 * (int64_t)M * N * (int64_t)sizeof(float) <= ws_bytes) pl = Plan{256, 160, 283, 2};
-        } else if (N % 128 == 0 && mt * (N / 128) >= 256) {
-            pl = Plan{256, 128, 283, 1};
+            if (!g_lc_only && M >= 256 && N % 128 == 0 && ((nk >= 20 && M >= 512) || (nk >= 10 && M >= 8192))) pl = Plan{256, 128, 283, 1};
+            if (g_big_tiles && (g_big_variant & 1) && M >= 256 && N % 128 == 0) pl = Plan{256, 128, 283, 1};
+        } else if (bn && M >= 256 && mt256 * (N / bn) >= 256) {
+            if (!g_lc_only) pl = Plan{256, bn, 283, 1};
+        } else if (bn && g_big_tiles && M >= 256) {
+            const int64_t t = mt256 * (N / bn);
+            int ks = (int)((256 + t / 2) / t);
+            if (ks > 8) ks = 8;
+            while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
+            if (!((g_big_variant & 2) && t * ks < 128)) pl = Plan{256, bn, 283, ks};  // b2 / b3: under half a chip of workgroups keep the plan above
+        } else if (bn && !g_pp_only) {
+            bool found = false;
+            for (int bm = 128; bm >= 64 && !found; bm >>= 1) {  // unsplit first: the larger tile wins when both fill the chip
+                const int64_t t = (int64_t)((M + bm - 1) / bm) * (N / bn);
+                if (t >= 200 && t <= 256) { pl = Plan{bm, bn, 244, 1}; found = true; }
+            }
+            // 64-row tiles pull 28 KB per K step through the CU for half the products of a 128-row tile (36 KB): with a deep K two
+            // slices of 128-row tiles beat them (tools/sweep_lc.py, conv 16x16 1280->1280 at batch 8: 78.2 -> 66.9 us, 2560->1280:
+            // 155 -> 121 us; at K = 5760 the slab reduction costs more than it buys: 39.4 vs 42.1 us)
+            if (found && pl.bm == 64 && nk >= 144 && 2 * (int64_t)M * N * (int64_t)sizeof(float) <= ws_bytes) {
+                const int64_t t = (int64_t)((M + 127) / 128) * (N / bn) * 2;
+                if (t >= 200 && t <= 256) pl = Plan{128, bn, 244, 2};
+            }
+            for (int bm = 128; bm >= 64 && !found; bm >>= 1) {  // K slices: at least 20 K steps (K = 1280) each
+                const int64_t t = (int64_t)((M + bm - 1) / bm) * (N / bn);
+                for (int ks = 2; ks <= 8 && !found; ++ks)
+                    if (t * ks >= 200 && t * ks <= 256 && nk / ks >= 20 && (int64_t)ks * M * N * (int64_t)sizeof(float) <= ws_bytes) {
+                        pl = Plan{bm, bn, 244, ks};
+                        found = true;
+                    }
+            }
         }
     }
     return pl;
@@ -1411,6 +1706,17 @@ hipError_t launch_ring(const GemmParams& p, int gz, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <typename HT, bool CONV, int TM, int TN>
+hipError_t launch_lc(const GemmParams& p, int gz, hipStream_t s) {
+    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
+    constexpr size_t smem = (size_t)4 * (BM + BN) * 128;
+    hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_lc_kernel<HT, CONV, TM, TN>), (int)smem);
+    if (e != hipSuccess) return e;
+    dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);
+    gemm_lc_kernel<HT, CONV, TM, TN><<<grid, 512, smem, s>>>(p);
+    return hipGetLastError();
+}
+
 template <typename HT, bool CONV, int TN>
 hipError_t launch_pp(const GemmParams& p, int gz, hipStream_t s) {
     constexpr int BM = 256, BN = 2 * TN * 16;
@@ -1427,8 +1733,9 @@ hipError_t launch_pp(const GemmParams& p, int gz, hipStream_t s) {
 // Column statistics (GemmParams::colstats) come out of the row epilogue of the default ring kernels only: every tile must be a
 // full tile of a single, unsplit launch whose waves own 64 rows x (BN/2) columns, a whole number of buckets.
 bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
-    const bool ring = pl.pf == 0 && pl.bm == 128, pp = pl.pf == 283 && pl.bm == 256;  // both: waves own 64 rows x (BN/2) columns
-    return (ring || pp) && (pl.bn == 160 || pl.bn == 128) && pl.ksplit == 1 && batch == 1 && bucket > 0 &&
+    // all three: waves own 64 rows x (BN/2) columns
+    const bool ring = pl.pf == 0 && pl.bm == 128, pp = pl.pf == 283 && pl.bm == 256, lc = pl.pf == 244 && pl.bm == 128;
+    return (ring || pp || lc) && (pl.bn == 160 || pl.bn == 128) && pl.ksplit == 1 && batch == 1 && bucket > 0 &&
            M % pl.bm == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0;
 }
 
@@ -1440,7 +1747,7 @@ bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
 const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch) {
     if (p.act == GMD_ACT_GEGLU) {
         const bool odd_tn = pl.bn == 160 || (pl.pf >= 100 && pl.pf != 283 && pl.bm == 64 && pl.bn == 64);  // TN = 5 / ring<1,4,1,.>: TN = 1
-        if (odd_tn || pl.ksplit > 1 || p.out_f32) return "has no GEGLU epilogue";
+        if (odd_tn || pl.ksplit > 1 || p.out_f32 || (pl.pf == 244 && pl.bm != 128)) return "has no GEGLU epilogue";
     }
     if (p.colstats) {
         const bool rows_ok = !p.out_f32 && p.act != GMD_ACT_GEGLU && (p.ldc & 7) == 0 && (p.residual == nullptr || (p.ldr & 7) == 0) &&
@@ -1465,7 +1772,14 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
     bool done = false;
-    if (pl.pf == 283) {  // ping-pong kernel: 8 consumer + 4 loader waves on a 256-row tile
+    if (pl.pf == 244) {  // loader / consumer kernel: 4 consumer + 4 loader waves, 4-stage ring, one workgroup per CU
+        if (pl.bm == 128 && pl.bn == 160) e = launch_lc<HT, CONV, 4, 5>(p, gz, s);
+        else if (pl.bm == 128 && pl.bn == 128) e = launch_lc<HT, CONV, 4, 4>(p, gz, s);
+        else if (pl.bm == 64 && pl.bn == 160) e = launch_lc<HT, CONV, 2, 5>(p, gz, s);
+        else if (pl.bm == 64 && pl.bn == 128) e = launch_lc<HT, CONV, 2, 4>(p, gz, s);
+        else { gmd_set_error("%s: loader/consumer tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
+        done = true;
+    } else if (pl.pf == 283) {  // ping-pong kernel: 8 consumer + 4 loader waves on a 256-row tile
         if (pl.bm == 256 && pl.bn == 160) e = launch_pp<HT, CONV, 5>(p, gz, s);
         else if (pl.bm == 256 && pl.bn == 128) e = launch_pp<HT, CONV, 4>(p, gz, s);
         else { gmd_set_error("%s: ping-pong tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
@@ -1493,7 +1807,7 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
         else if (pl.pf != 0 && !(pl.bm == 128))
             e = pl.pf == 1 ? launch_bf16<HT, CONV, 64, 64, 1>(p, gz, s) : launch_bf16<HT, CONV, 64, 64, 2>(p, gz, s);
         else done = false;
-    } else if (pl.pf != 0 && pl.pf != 283) {
+    } else if (pl.pf != 0 && pl.pf != 283 && pl.pf != 244) {
         gmd_set_error("%s: plan override pf=%d is instantiated for bfloat16 only", name, pl.pf);
         return GMD_ERR_UNSUPPORTED;
     }

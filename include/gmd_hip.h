@@ -223,7 +223,8 @@ int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t wo
 /* Which kernel a 16-bit gmd_gemm_nt / gmd_conv3x3 launch of these dimensions takes (for a convolution M = B*Hout*Wout, N = Cout,
  * K = 9*Cin; `geglu` = 1 for GMD_ACT_GEGLU launches): out4 = {tile rows, tile columns, kernel code, K slices}.  Kernel codes:
  * 0 = the LDS-DMA ring kernels (two 4-wave workgroups per CU; 64x64 tiles for under-filled launches), 283 = the ping-pong kernel
- * (one workgroup of 8 consumer + 4 loader waves on a 256-row tile, round 4).  Pure host function: tests and measurement tools use
+ * (one workgroup of 8 consumer + 4 loader waves on a 256-row tile, round 4), 244 = the loader / consumer kernel (4 consumer + 4
+ * loader waves on a 128- or 64-row tile, for launches with about one tile per CU, round 4).  Pure host function: tests and measurement tools use
  * it to know what they exercise; nothing in the product path calls it.  Returns GMD_ERR_INVALID for other element types. */
 int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4);
 

@@ -35,8 +35,9 @@ for B, H, W, ci, co, kw in [(8, 64, 64, 320, 320, {}), (8, 64, 64, 640, 320, {})
     b = torch.randn(co, generator=g).cuda()
     cases.append((f"conv B={B} {H}x{W} {ci}->{co} {kw}", 2.0 * B * H * W * co * 9 * ci / (kw.get('stride', 1) ** 2) * (4 if kw.get('upsample') else 1),
                   lambda x=x, w=w, b=b, B=B, H=H, W=W, kw=kw: ops.conv3x3(x, w, B, H, W, bias=b, **kw)[0]))
-for M, N, K in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192, 640, 640), (8192, 5120, 640), (2048, 1280, 5120), (1000, 320, 192),
-                (16384, 320, 320), (4096, 640, 640), (1024, 1280, 1280), (8192, 1280, 640), (2048, 2560, 1280)]:
+for M, N, K in [(32768, 320, 320), (32768, 2560, 320), (32768, 320, 1280), (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560), (2048, 1280, 1280),
+                (2048, 1280, 5120), (1000, 320, 192), (16384, 320, 320), (4096, 640, 640), (1024, 1280, 1280), (8192, 1280, 640), (2048, 2560, 1280),
+                (4096, 640, 2560), (512, 1280, 1280), (16384, 320, 1280)]:
     a = torch.randn(M, K, generator=g).bfloat16().cuda()
     w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
     b = torch.randn(N, generator=g).cuda()
