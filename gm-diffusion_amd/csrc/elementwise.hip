@@ -194,3 +194,24 @@ int gmd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, 
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------
+// device-time stamp (measurement only): one thread writes the constant-rate 100 MHz counter (s_memrealtime, common to the whole
+// device) into *slot.  Launched between the kernels of BOTH streams of the pipeline -- also from inside captured HIP graphs -- it gives
+// the concurrent timeline of the shipped two-stream path, which rocprofv3 cannot (its tracing serialises the streams).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void stamp_kernel(unsigned long long* base, const int* row, int stride, int k) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    base[(row ? (long long)*row * stride : 0) + k] = t;
+}
+}  // namespace
+
+extern "C" int gmd_stamp(uint64_t* base, const int* row, int stride, int k, gmd_stream_t stream) {
+    GMD_REQUIRE(base != nullptr && (reinterpret_cast<uintptr_t>(base) & 7) == 0 && stride >= 0 && k >= 0, "gmd_stamp: bad argument");
+    stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(reinterpret_cast<unsigned long long*>(base), row, stride, k);
+    GMD_CHECK_LAUNCH("gmd_stamp");
+    return GMD_OK;
+}

@@ -1465,6 +1465,486 @@ __global__ __launch_bounds__(512, 2) void gemm_lc_kernel(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3x3 (stride 1, pad 1) with the INPUT PATCH resident in LDS (round 4): the ping-pong structure of gemm_pp_kernel -- 8 consumer
+// + 4 loader waves on a tile of 256 output pixels x (32 TN) channels -- but the activation operand is not re-fetched per filter tap.
+//
+// Why: the implicit GEMM above pulls every input pixel through the CU nine times (once per tap): 32 KB of A + 20 KB of W per 64-deep
+// K step.  The two-stream pipeline is bound by what the CUs can ingest from L2 (~36 B/clk each, make_plan), so the bytes are what
+// counts.  Here a tile's input patch -- its rows of pixels plus a one-pixel halo, 64 channels deep: (R+2) x (W+2) pixels x 128 B,
+// at most 50 KB -- is loaded ONCE per 64-channel block into a double-buffered LDS image and all nine taps read their A fragments
+// from it at shifted rows (a tap is an LDS address offset); only the weights stream per K step (20 KB): 25.6 KB per K step instead of 52.
+//
+//   K order: 64-channel block (outer), tap (inner): K step kt = 9 cb + tap.   LDS: [patch 0][patch 1][W ring, 3 stages].
+//   patch pixel index of (image i of the tile, patch row pr, patch column pc) = (i (R+2) + pr)(W+2) + pc  <->  input (r0 + pr - 1, pc - 1);
+//   out-of-image pixels are read through an out-of-range buffer offset (zeros).  Output pixel (i, y, x) and tap (ky, kx) read patch
+//   pixel base(i, y, x) + ky (W+2) + kx with base = (i (R+2) + y)(W+2) + x.  A patch pixel is one 128-byte LDS row, chunk-swizzled
+//   by its row index like every other tile of this file.
+//   loader, per K step: the W tile of step kt+2 (ring) + a share of the NEXT block's patch (taps 0..7; tap 8 issues none, so its
+//   counted vmcnt leaves only W pieces outstanding and the whole patch has landed when the block ends).
+//
+// Barrier / hazard structure: exactly gemm_pp_kernel's (4 barriers per K step, waves 4-7 staggered by one); the patch buffer of
+// block cb+1 was last read in block cb-1, whose last reads had returned before the barrier that opens block cb.
+// Tiles: 256 consecutive output pixels = whole image rows (W <= 64, 256 % W == 0) of one image, or whole images when H W < 256.
+// ------------------------------------------------------------------------------------------------
+template <typename HT, int TN, int NPP>
+__global__ __launch_bounds__(768, 3) void conv_patch_kernel(const GemmParams p) {
+    constexpr int WN = 2, NCONS = 8, LW = 4, TM = 4, NWS = 3;
+    constexpr int BM = 256, BN = WN * TN * 16;
+    constexpr int NWP = BN / (LW * 8);               // W pieces per loader wave and K step (5 / 4)
+    constexpr int kWStage = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+    const bool loader = wuni >= NCONS;
+    const bool late = wuni >= 4 && !loader;
+    int m0, n0;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tiles_n = (p.N + BN - 1) / BN;
+        const int mt = L / tiles_n;
+        m0 = mt * BM;
+        n0 = (L - mt * tiles_n) * BN;
+    }
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    // geometry (host-checked: stride 1, pad 1, W a power of two <= 64, 256 % W == 0, H W a multiple or a divisor of 256)
+    const int H = p.Hin, W = p.Win, HW = H * W;
+    const int R = HW >= BM ? BM / W : H;              // image rows per image of the tile
+    const int PW = W + 2, PR = R + 2;
+    const int nimg = BM / (R * W);
+    const int patch_px = nimg * PR * PW;
+    const int npieces = (patch_px + 7) >> 3;
+    const int PB = npieces * 1024;                    // bytes of one patch buffer
+    const int b0 = m0 / HW, r0 = HW >= BM ? (m0 - b0 * HW) / W : 0;
+    // K range of this slice, in 64-channel blocks
+    const int nblk_total = p.Cin / BK;
+    const int per = (nblk_total + p.ksplit - 1) / p.ksplit;
+    const int cb_begin = ks * per;
+    const int ncb = (cb_begin + per <= nblk_total ? per : nblk_total - cb_begin);  // blocks of this slice (may be <= 0)
+    const int nk = ncb * 9;
+
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    const unsigned w_ring = 2u * (unsigned)PB;        // byte offset of the W ring behind the two patch buffers
+
+    if (loader) {
+        const int lw = wuni - NCONS;
+        const int ltid = tid - NCONS * 64;
+        // patch pieces of this wave: piece q = j * 4 + lw; a piece beyond the patch re-loads an early piece (same bytes to the same
+        // place: harmless) so that every wave issues exactly NPP pieces per block and the counted waits below hold
+        unsigned poff[NPP];
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) {
+            int q = j * LW + lw;
+            if (q >= npieces) q -= npieces;
+            const int pix = q * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((pix >> 1) & 7);
+            const int i = pix / (PR * PW), rem = pix - i * (PR * PW);
+            const int pr = rem / PW, pc = rem - pr * PW;
+            const int iy = r0 + pr - 1, ix = pc - 1, b = b0 + i;
+            const bool ok = pix < patch_px && b < p.M / HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            poff[j] = ok ? (unsigned)(((b * H + iy) * W + ix) * p.Cin) * 2u + (unsigned)chunk * 16u : kOOB;
+        }
+        unsigned woff[NWP];
+        {
+            const int srow = ltid >> 3;
+            const int chunk = (ltid & 7) ^ ((srow >> 1) & 7);
+#pragma unroll
+            for (int i = 0; i < NWP; ++i) {
+                const int n = n0 + srow + (LW * 8) * i;
+                woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u + (unsigned)chunk * 16u : kOOB;
+            }
+        }
+        u32x4 dA, dW;
+        {
+            const uint64_t ba = (uint64_t)p.A, bw = (uint64_t)p.W;
+            dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+            dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+        }
+        auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                         :
+                         : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                         : "memory", "m0");
+#pragma clang diagnostic pop
+        };
+        // patch pieces [lo, hi) of this wave for 64-channel block cb into patch buffer `buf`
+        auto dma_patch = [&](auto LO, auto HI, int cb, int buf) {
+            constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+            const unsigned soff = (unsigned)(cb_begin + cb) * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < NPP; ++j)
+                if (j >= lo && j < hi) {
+                    int q = j * LW + lw;
+                    if (q >= npieces) q -= npieces;
+                    dma16(dA, lds_base + (unsigned)buf * (unsigned)PB + (unsigned)q * 1024u, poff[j], soff);
+                }
+        };
+        // W pieces [lo, hi) of K step (cb, tap) into ring stage `st`
+        auto dma_w = [&](auto LO, auto HI, int cb, int tap, int st) {
+            constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+            const unsigned soff = (unsigned)(tap * p.Cin + (cb_begin + cb) * BK) * 2u;
+            const unsigned stage = lds_base + w_ring + (unsigned)st * kWStage + (unsigned)lw * (8 * 128);
+#pragma unroll
+            for (int i = 0; i < NWP; ++i)
+                if (i >= lo && i < hi) dma16(dW, stage + i * (LW * 8 * 128), woff[i], soff);
+        };
+        // patch pieces issued at tap t of a block (for the NEXT block): 2,2,2,2,2,1,1,1,0 (NPP = 13) / 2,2,2,1,1,1,1,1,0 (NPP = 11)
+        if (nk > 0) {
+            dma_patch(IntC<0>{}, IntC<NPP>{}, 0, 0);
+            dma_w(IntC<0>{}, IntC<NWP>{}, 0, 0, 0);
+            dma_w(IntC<0>{}, IntC<NWP>{}, 0, 1, 1);
+            wait_vmcnt<NWP>();  // the patch of block 0 and the W tile of step 0 have landed
+            seg_barrier();      // #0
+            int st_fill = 2;
+            for (int cb = 0; cb < ncb; ++cb) {
+                const bool next_blk = cb + 1 < ncb;
+                const int nbuf = (cb + 1) & 1;
+                auto kstep = [&](auto TAP) {
+                    constexpr int t = decltype(TAP)::value;
+                    constexpr int n2 = NPP == 13 ? 5 : 3;                 // taps that issue two patch pieces
+                    constexpr int pc = t < n2 ? 2 : (t < 8 ? 1 : 0);      // patch pieces issued at this tap
+                    constexpr int pj = t < n2 ? 2 * t : n2 + t;           // index of the first of them
+                    const int kt = cb * 9 + t;
+                    // the W tile of step kt+2: (cb, t+2) or the next block's (t+2-9)
+                    const bool more = kt + 2 < nk;
+                    const int wcb = t + 2 < 9 ? cb : cb + 1, wtap = t + 2 < 9 ? t + 2 : t + 2 - 9;
+                    if (more) dma_w(IntC<0>{}, IntC<(NWP + 3) / 4>{}, wcb, wtap, st_fill);
+                    if (next_blk && pc >= 1) dma_patch(IntC<pj>{}, IntC<pj + 1>{}, cb + 1, nbuf);
+                    seg_barrier();
+                    if (more) dma_w(IntC<(NWP + 3) / 4>{}, IntC<(NWP + 3) / 4 + (NWP + 2) / 4>{}, wcb, wtap, st_fill);
+                    if (next_blk && pc >= 2) dma_patch(IntC<pj + 1>{}, IntC<pj + 2>{}, cb + 1, nbuf);
+                    seg_barrier();
+                    if (more) dma_w(IntC<(NWP + 3) / 4 + (NWP + 2) / 4>{}, IntC<(NWP + 3) / 4 + (NWP + 2) / 4 + (NWP + 1) / 4>{}, wcb, wtap, st_fill);
+                    seg_barrier();
+                    if (more) dma_w(IntC<(NWP + 3) / 4 + (NWP + 2) / 4 + (NWP + 1) / 4>{}, IntC<NWP>{}, wcb, wtap, st_fill);
+                    // everything issued BEFORE this K step has landed (the W tile of step kt+1; at tap 8, pc == 0: the whole patch
+                    // of the next block): only this step's own pieces may remain
+                    if (more && next_blk) wait_vmcnt<NWP + pc>();
+                    else if (more) wait_vmcnt<NWP>();
+                    else wait_vmcnt<0>();
+                    seg_barrier();
+                    st_fill = st_fill == NWS - 1 ? 0 : st_fill + 1;
+                };
+                kstep(IntC<0>{}); kstep(IntC<1>{}); kstep(IntC<2>{}); kstep(IntC<3>{}); kstep(IntC<4>{});
+                kstep(IntC<5>{}); kstep(IntC<6>{}); kstep(IntC<7>{}); kstep(IntC<8>{});
+            }
+            seg_barrier();  // the trailing barrier of the early consumer group
+        }
+        __syncthreads();
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumer waves
+    const int wr = wid / WN, wc = wid % WN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    int prow[TM];  // patch pixel of this lane's output pixel of 16-row tile i at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wr * 64 + i * 16 + frow;
+        const int img = ml / (R * W), rem = ml - img * (R * W);
+        const int y = rem / W, x = rem - y * W;
+        prow[i] = (img * PR + y) * PW + x;
+    }
+    uint4 fa[TM], fb[TN];
+    auto frag_reads = [&](int pbuf, int tapoff, int wst, int s2) {
+        const unsigned char* sP = smem + pbuf * PB;
+        const unsigned char* sW = smem + w_ring + wst * kWStage;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = prow[i] + tapoff;
+            fa[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + (((4 * s2 + fq) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(sW + lds_off(wc * (TN * 16) + j * 16 + frow, 4 * s2 + fq));
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Half<HT>::mfma16(fb[j], fa[i], acc[i][j]);
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    if (nk > 0) {
+        seg_barrier();                  // #0
+        if (late) seg_barrier();        // the stagger
+        int wst = 0, pbuf = 0, tap = 0, kx = 0, tapoff = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                frag_reads(pbuf, tapoff, wst, s2);
+                lgkm0();
+                seg_barrier();
+                __builtin_amdgcn_s_setprio(1);
+                mfmas();
+                __builtin_amdgcn_s_setprio(0);
+                seg_barrier();
+            }
+            wst = wst == NWS - 1 ? 0 : wst + 1;
+            ++tap;
+            if (tap == 9) { tap = 0; kx = 0; tapoff = 0; pbuf ^= 1; }
+            else if (kx == 2) { kx = 0; tapoff += PW - 2; }
+            else { ++kx; ++tapoff; }
+        }
+        if (!late) seg_barrier();
+    }
+    const int z = 0;
+    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
+                         (p.residual == nullptr || (p.ldr & 7) == 0) &&
+                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    __syncthreads();
+    if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+        constexpr int kStripS = 32 * (TN * 16 + 4);
+        epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        return;
+    }
+    if (rows_ok) {
+        constexpr int kStrip = 32 * (TN * 16 + 4);
+        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+    } else {
+        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+    }
+}
+
+// Same kernel with CONTINUOUS consumers: every consumer wave keeps both 32-deep half steps of a K step in registers (two fragment
+// sets), issues all their reads up front and multiplies; ONE barrier per K step, no stagger.  (The ping-pong form above spends
+// ~130 cycles of barrier skew in each of its four intervals per K step: tools/pp_diag.py.)
+template <typename HT, int TN, int NPP>
+__global__ __launch_bounds__(768, 3) void conv_patch_cont_kernel(const GemmParams p) {
+    constexpr int WN = 2, NCONS = 8, LW = 4, TM = 4, NWS = 3;
+    constexpr int BM = 256, BN = WN * TN * 16;
+    constexpr int NWP = BN / (LW * 8);               // W pieces per loader wave and K step (5 / 4)
+    constexpr int kWStage = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+    const bool loader = wuni >= NCONS;
+    int m0, n0;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tiles_n = (p.N + BN - 1) / BN;
+        const int mt = L / tiles_n;
+        m0 = mt * BM;
+        n0 = (L - mt * tiles_n) * BN;
+    }
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    // geometry (host-checked: stride 1, pad 1, W a power of two <= 64, 256 % W == 0, H W a multiple or a divisor of 256)
+    const int H = p.Hin, W = p.Win, HW = H * W;
+    const int R = HW >= BM ? BM / W : H;              // image rows per image of the tile
+    const int PW = W + 2, PR = R + 2;
+    const int nimg = BM / (R * W);
+    const int patch_px = nimg * PR * PW;
+    const int npieces = (patch_px + 7) >> 3;
+    const int PB = npieces * 1024;                    // bytes of one patch buffer
+    const int b0 = m0 / HW, r0 = HW >= BM ? (m0 - b0 * HW) / W : 0;
+    // K range of this slice, in 64-channel blocks
+    const int nblk_total = p.Cin / BK;
+    const int per = (nblk_total + p.ksplit - 1) / p.ksplit;
+    const int cb_begin = ks * per;
+    const int ncb = (cb_begin + per <= nblk_total ? per : nblk_total - cb_begin);  // blocks of this slice (may be <= 0)
+    const int nk = ncb * 9;
+
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    const unsigned w_ring = 2u * (unsigned)PB;        // byte offset of the W ring behind the two patch buffers
+
+    if (loader) {
+        const int lw = wuni - NCONS;
+        const int ltid = tid - NCONS * 64;
+        // patch pieces of this wave: piece q = j * 4 + lw; a piece beyond the patch re-loads an early piece (same bytes to the same
+        // place: harmless) so that every wave issues exactly NPP pieces per block and the counted waits below hold
+        unsigned poff[NPP];
+#pragma unroll
+        for (int j = 0; j < NPP; ++j) {
+            int q = j * LW + lw;
+            if (q >= npieces) q -= npieces;
+            const int pix = q * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((pix >> 1) & 7);
+            const int i = pix / (PR * PW), rem = pix - i * (PR * PW);
+            const int pr = rem / PW, pc = rem - pr * PW;
+            const int iy = r0 + pr - 1, ix = pc - 1, b = b0 + i;
+            const bool ok = pix < patch_px && b < p.M / HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            poff[j] = ok ? (unsigned)(((b * H + iy) * W + ix) * p.Cin) * 2u + (unsigned)chunk * 16u : kOOB;
+        }
+        unsigned woff[NWP];
+        {
+            const int srow = ltid >> 3;
+            const int chunk = (ltid & 7) ^ ((srow >> 1) & 7);
+#pragma unroll
+            for (int i = 0; i < NWP; ++i) {
+                const int n = n0 + srow + (LW * 8) * i;
+                woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u + (unsigned)chunk * 16u : kOOB;
+            }
+        }
+        u32x4 dA, dW;
+        {
+            const uint64_t ba = (uint64_t)p.A, bw = (uint64_t)p.W;
+            dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+            dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+        }
+        auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                         :
+                         : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                         : "memory", "m0");
+#pragma clang diagnostic pop
+        };
+        // patch pieces [lo, hi) of this wave for 64-channel block cb into patch buffer `buf`
+        auto dma_patch = [&](auto LO, auto HI, int cb, int buf) {
+            constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+            const unsigned soff = (unsigned)(cb_begin + cb) * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < NPP; ++j)
+                if (j >= lo && j < hi) {
+                    int q = j * LW + lw;
+                    if (q >= npieces) q -= npieces;
+                    dma16(dA, lds_base + (unsigned)buf * (unsigned)PB + (unsigned)q * 1024u, poff[j], soff);
+                }
+        };
+        // W pieces [lo, hi) of K step (cb, tap) into ring stage `st`
+        auto dma_w = [&](auto LO, auto HI, int cb, int tap, int st) {
+            constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+            const unsigned soff = (unsigned)(tap * p.Cin + (cb_begin + cb) * BK) * 2u;
+            const unsigned stage = lds_base + w_ring + (unsigned)st * kWStage + (unsigned)lw * (8 * 128);
+#pragma unroll
+            for (int i = 0; i < NWP; ++i)
+                if (i >= lo && i < hi) dma16(dW, stage + i * (LW * 8 * 128), woff[i], soff);
+        };
+        // patch pieces issued at tap t of a block (for the NEXT block): 2,2,2,2,2,1,1,1,0 (NPP = 13) / 2,2,2,1,1,1,1,1,0 (NPP = 11)
+        if (nk > 0) {
+            dma_patch(IntC<0>{}, IntC<NPP>{}, 0, 0);
+            dma_w(IntC<0>{}, IntC<NWP>{}, 0, 0, 0);
+            dma_w(IntC<0>{}, IntC<NWP>{}, 0, 1, 1);
+            wait_vmcnt<NWP>();  // the patch of block 0 and the W tile of step 0 have landed
+            seg_barrier();      // #0
+            int st_fill = 2;
+            for (int cb = 0; cb < ncb; ++cb) {
+                const bool next_blk = cb + 1 < ncb;
+                const int nbuf = (cb + 1) & 1;
+                auto kstep = [&](auto TAP) {
+                    constexpr int t = decltype(TAP)::value;
+                    constexpr int n2 = NPP == 13 ? 5 : 3;                 // taps that issue two patch pieces
+                    constexpr int pc = t < n2 ? 2 : (t < 8 ? 1 : 0);      // patch pieces issued at this tap
+                    constexpr int pj = t < n2 ? 2 * t : n2 + t;           // index of the first of them
+                    const int kt = cb * 9 + t;
+                    // the W tile of step kt+2: (cb, t+2) or the next block's (t+2-9)
+                    const bool more = kt + 2 < nk;
+                    const int wcb = t + 2 < 9 ? cb : cb + 1, wtap = t + 2 < 9 ? t + 2 : t + 2 - 9;
+                    if (more) dma_w(IntC<0>{}, IntC<NWP>{}, wcb, wtap, st_fill);
+                    if (next_blk && pc >= 1) dma_patch(IntC<pj>{}, IntC<pj + pc>{}, cb + 1, nbuf);
+                    // everything issued BEFORE this K step has landed (the W tile of step kt+1; at tap 8, pc == 0: the whole patch
+                    // of the next block): only this step's own pieces may remain
+                    if (more && next_blk) wait_vmcnt<NWP + pc>();
+                    else if (more) wait_vmcnt<NWP>();
+                    else wait_vmcnt<0>();
+                    seg_barrier();  // B(kt+1): publishes W tile kt+1, frees the stage of tile kt
+                    st_fill = st_fill == NWS - 1 ? 0 : st_fill + 1;
+                };
+                kstep(IntC<0>{}); kstep(IntC<1>{}); kstep(IntC<2>{}); kstep(IntC<3>{}); kstep(IntC<4>{});
+                kstep(IntC<5>{}); kstep(IntC<6>{}); kstep(IntC<7>{}); kstep(IntC<8>{});
+            }
+        }
+        __syncthreads();
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumer waves
+    const int wr = wid / WN, wc = wid % WN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    int prow[TM];  // patch pixel of this lane's output pixel of 16-row tile i at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wr * 64 + i * 16 + frow;
+        const int img = ml / (R * W), rem = ml - img * (R * W);
+        const int y = rem / W, x = rem - y * W;
+        prow[i] = (img * PR + y) * PW + x;
+    }
+    uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto frag_reads = [&](int pbuf, int tapoff, int wst, int s2, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
+        const unsigned char* sP = smem + pbuf * PB;
+        const unsigned char* sW = smem + w_ring + wst * kWStage;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(sW + lds_off(wc * (TN * 16) + j * 16 + frow, 4 * s2 + fq));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = prow[i] + tapoff;
+            fa[i] = *reinterpret_cast<const uint4*>(sP + row * 128 + (((4 * s2 + fq) ^ ((row >> 1) & 7)) << 4));
+        }
+    };
+    auto mfmas = [&](const uint4 (&fa)[TM], const uint4 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Half<HT>::mfma16(fb[j], fa[i], acc[i][j]);
+    };
+    if (nk > 0) {
+        seg_barrier();                  // B(0): the patch of block 0 and W tile 0 are in LDS
+        int wst = 0, pbuf = 0, tap = 0, kx = 0, tapoff = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            frag_reads(pbuf, tapoff, wst, 0, fa0, fb0);
+            frag_reads(pbuf, tapoff, wst, 1, fa1, fb1);   // the second half step's reads return under the first one's MFMAs
+            mfmas(fa0, fb0);
+            mfmas(fa1, fb1);
+            seg_barrier();              // B(kt+1)
+            wst = wst == NWS - 1 ? 0 : wst + 1;
+            ++tap;
+            if (tap == 9) { tap = 0; kx = 0; tapoff = 0; pbuf ^= 1; }
+            else if (kx == 2) { kx = 0; tapoff += PW - 2; }
+            else { ++kx; ++tapoff; }
+        }
+    }
+    const int z = 0;
+    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
+                         (p.residual == nullptr || (p.ldr & 7) == 0) &&
+                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    __syncthreads();
+    if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+        constexpr int kStripS = 32 * (TN * 16 + 4);
+        epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        return;
+    }
+    if (rows_ok) {
+        constexpr int kStrip = 32 * (TN * 16 + 4);
+        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+    } else {
+        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // float32 FMA kernel (parity path): 64x64x16 tiles, 4x4 outputs per thread
 // ------------------------------------------------------------------------------------------------
 template <bool CONV>
@@ -1582,13 +2062,14 @@ struct Force {
 Force g_force;  // read once when the library is loaded
 // GMD_PP=0 keeps the round-3 plans (A/B measurements of whole runs; read once when the library is loaded)
 const bool g_pp_enabled = [] { const char* e = getenv("GMD_PP"); return !(e && e[0] == '0'); }();
-// A/B only: GMD_PP=p keeps the ping-pong kernel alone, GMD_PP=l the loader / consumer kernel alone
-const bool g_pp_only = [] { const char* e = getenv("GMD_PP"); return e && e[0] == 'p'; }();
-const bool g_lc_only = [] { const char* e = getenv("GMD_PP"); return e && e[0] == 'l'; }();
-// A/B only: GMD_PP=b takes the 256-row ping-pong tile with K slices wherever the loader / consumer kernel would be taken
-// (least L2 -> LDS bytes per product: is the two-stream pipeline bound by what the CUs can ingest?)
+// How stride-1 convolutions on 256-row ping-pong tiles fetch their activations: 2 (default) = input patch resident in LDS, continuous
+// consumers (conv_patch_cont_kernel); 1 = patch resident, ping-pong consumers (conv_patch_kernel); 0 = per-tap implicit GEMM
+// (gemm_pp_kernel<CONV>).  GMD_CONV_PATCH seeds it when the library is loaded; gmd_conv_patch_override() changes it in-process for A/B
+// runs and tests (GMD_TUNING=1 only).  Whole-run A/B (profiles/r04_ab_bench_plan_families.txt): 838.7 / 840.6 / 837.5 ms for 0 / 1 / 2
+// -- level by time, but the patch forms pull half the bytes from L2 (25.6 instead of 52 KB per K step).
+int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
+// A/B only: GMD_PP=b selects 256-row tiles with K slices everywhere (see make_plan)
 const bool g_big_tiles = [] { const char* e = getenv("GMD_PP"); return e && e[0] == 'b'; }();
-const int g_big_variant = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b' && e[1]) ? e[1] - '0' : 0; }();  // b1, b2, ...
 
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
@@ -1632,30 +2113,44 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
         pl.bn = 64;
     }
     if (fks) pl.ksplit = ((int64_t)fks * M * N * (int64_t)sizeof(float) <= ws_bytes && batch == 1) ? fks : 1;
-    // Round-4 kernels: one workgroup per CU with dedicated LDS-DMA loader waves.  Taken where they measured faster than the plans
-    // above on the UNet's / VAE's shapes (tools/sweep_pp.py, tools/check_ring.py: device time, batch 8 and 4):
-    //   * ping-pong kernel (gemm_pp_kernel, code 283), 256-row tiles: >= 256 tiles of 256 x 160 (every level-0 linear / convolution
-    //     at batch 8: +3...+18 %), or of 256 x 128 where N is not a multiple of 160 (VAE decoder: +2...+12 %); the GEGLU projection
-    //     (256 x 128, value | gate pairs) from K = 1280 up, or K = 640 with at least 8192 rows (+5...+14 %);
-    //   * loader / consumer kernel (gemm_lc_kernel, code 244), 128- or 64-row tiles, for launches that have about ONE tile per CU
-    //     (200...256 tiles; with K slices where K is deep): conv 32x32 640->640 at batch 8 72.8 -> 55.5 us, 64x64 320->320 at batch 4
-    //     41.3 -> 33.0 us, linear M=2048 N=1280 K=5120 49.4 -> 36.8 us.  More than 256 such tiles would run in two rounds of one
-    //     workgroup per CU (M=8192 N=1280 K=640: 36.5 us against 24.8 us), fewer than ~200 leave CUs idle: both keep the plans above.
+    // Round-4 kernels: one workgroup per CU with dedicated LDS-DMA loader waves (gemm_pp_kernel, code 283: 256-row tiles;
+    // gemm_lc_kernel, code 244: 128- / 64-row tiles for launches with about one tile per CU).
+    //
+    // DEFAULT POLICY -- the plan that is fastest launch by launch (tools/sweep_pp.py --round3, device time inside a HIP graph: -11 % /
+    // -15 % summed over the UNet's linear + convolution launches at batch 8 / 4 against the round-3 plans; every row of the vendor-
+    // library yardstick, tools/vs_library_gemm.py):
+    //   * ping-pong kernel where there are >= 256 tiles of 256 x 160 (every level-0 linear / convolution at batch 8), or of 256 x 128
+    //     where N is not a multiple of 160 (VAE decoder); the GEGLU projection (value | gate pairs) from K = 1280 up, or K = 640 with
+    //     at least 8192 rows;
+    //   * loader / consumer kernel where 128- or 64-row tiles give 200...256 workgroups (with K slices where K is deep): conv 32x32
+    //     640->640 at batch 8 72.8 -> 55.5 us, 64x64 320->320 at batch 4 41.3 -> 33.0 us, linear M=2048 N=1280 K=5120 49.4 -> 36.8 us.
+    //     More than 256 such tiles would run in two rounds of one workgroup per CU, fewer than ~200 leave CUs idle: both keep the
+    //     plans above.
+    // ALTERNATIVE (GMD_PP=b) -- the largest tile, filled up with K slices: slower launch by launch, but 0.4...1.3 % faster on the wall
+    // of the two-stream pipeline in three interleaved whole-run A/B comparisons (profiles/r04_ab_bench_plan_families.txt: 828.1 vs
+    // 838.7, 838.7 vs 845.2, 861.7 vs 864.8 ms per batch; round-3 plans 851.6 / 849.6 / 858.8).  With two streams in flight a second
+    // workgroup is always there to hide a kernel's own latencies, so L2 -> LDS bytes per product -- (1/BM + 1/BN) x 2 B: 0.020 for a
+    // 256 x 160 tile, 0.028 for 128 x 160, 0.044 for 64 x 160 -- weigh more than the launch's time alone on the chip (streams
+    // serialised, the launch-by-launch plans win clearly: 1066 -> 1018 ms).  Not the default: the gain is inside the box-to-box
+    // spread, and single-stream users (the GM pipeline, the VAE, every direct call) would pay for it.  GMD_PP=0: the round-3 plans.
     if (g_pp_enabled && batch == 1 && !(fbm && fbn) && !fpf && !fks && M >= 64) {
         const int64_t mt256 = (M + 255) / 256;
         const int bn = N % 160 == 0 ? 160 : (N % 128 == 0 ? 128 : 0);
-        if (pair_tiles) {
-            if (!g_lc_only && M >= 256 && N % 128 == 0 && ((nk >= 20 && M >= 512) || (nk >= 10 && M >= 8192))) pl = Plan{256, 128, 283, 1};
-            if (g_big_tiles && (g_big_variant & 1) && M >= 256 && N % 128 == 0) pl = Plan{256, 128, 283, 1};
+        if (g_big_tiles) {
+            if (pair_tiles) {
+                if (M >= 256 && N % 128 == 0) pl = Plan{256, 128, 283, 1};  // GEGLU pairs value / gate tiles: no K slices
+            } else if (bn && M >= 256) {
+                const int64_t t = mt256 * (N / bn);
+                int ks = t >= 256 ? 1 : (int)((256 + t / 2) / t);
+                if (ks > 8) ks = 8;
+                while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
+                pl = Plan{256, bn, 283, ks};
+            }
+        } else if (pair_tiles) {
+            if (M >= 256 && N % 128 == 0 && ((nk >= 20 && M >= 512) || (nk >= 10 && M >= 8192))) pl = Plan{256, 128, 283, 1};
         } else if (bn && M >= 256 && mt256 * (N / bn) >= 256) {
-            if (!g_lc_only) pl = Plan{256, bn, 283, 1};
-        } else if (bn && g_big_tiles && M >= 256) {
-            const int64_t t = mt256 * (N / bn);
-            int ks = (int)((256 + t / 2) / t);
-            if (ks > 8) ks = 8;
-            while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
-            if (!((g_big_variant & 2) && t * ks < 128)) pl = Plan{256, bn, 283, ks};  // b2 / b3: under half a chip of workgroups keep the plan above
-        } else if (bn && !g_pp_only) {
+            pl = Plan{256, bn, 283, 1};
+        } else if (bn) {
             bool found = false;
             for (int bm = 128; bm >= 64 && !found; bm >>= 1) {  // unsplit first: the larger tile wins when both fill the chip
                 const int64_t t = (int64_t)((M + bm - 1) / bm) * (N / bn);
@@ -1714,6 +2209,51 @@ hipError_t launch_lc(const GemmParams& p, int gz, hipStream_t s) {
     if (e != hipSuccess) return e;
     dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);
     gemm_lc_kernel<HT, CONV, TM, TN><<<grid, 512, smem, s>>>(p);
+    return hipGetLastError();
+}
+
+// conv_patch_kernel: stride-1 / pad-1 convolutions whose 256-pixel tiles are whole image rows (or whole images) -- every UNet level
+bool conv_patch_ok(const GemmParams& p) {
+    const int H = p.Hin, W = p.Win, HW = H * W;
+    if (p.stride != 1 || p.upsample || p.pad_lo != 1 || p.Hout != H || p.Wout != W) return false;
+    if (W < 8 || W > 64 || (W & (W - 1)) || p.Cin % BK || p.M % HW) return false;
+    if (HW >= 256 ? (HW % 256 != 0) : (256 % HW != 0)) return false;
+    const int R = HW >= 256 ? 256 / W : H, nimg = 256 / (R * W);
+    return nimg * (R + 2) * (W + 2) <= 400;
+}
+
+template <typename HT, int TN>
+hipError_t launch_conv_patch(const GemmParams& p, int gz, hipStream_t s) {
+    constexpr int BM = 256, BN = 2 * TN * 16;
+    const int H = p.Hin, W = p.Win, HW = H * W;
+    const int R = HW >= 256 ? 256 / W : H, nimg = 256 / (R * W);
+    const int npieces = (nimg * (R + 2) * (W + 2) + 7) / 8;
+    const size_t smem = (size_t)2 * npieces * 1024 + (size_t)3 * BN * 128;
+    const size_t strips = (size_t)8 * 32 * (TN * 16 + 4) * 4;  // the epilogue strips reuse the K-loop image
+    const size_t need = smem > strips ? smem : strips;
+    dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);
+    hipError_t e;
+    if (g_conv_patch_mode == 2) {
+        if (npieces > 44) {
+            e = opt_in_lds(reinterpret_cast<const void*>(&conv_patch_cont_kernel<HT, TN, 13>), 163840);
+            if (e != hipSuccess) return e;
+            conv_patch_cont_kernel<HT, TN, 13><<<grid, 768, need, s>>>(p);
+        } else {
+            e = opt_in_lds(reinterpret_cast<const void*>(&conv_patch_cont_kernel<HT, TN, 11>), 163840);
+            if (e != hipSuccess) return e;
+            conv_patch_cont_kernel<HT, TN, 11><<<grid, 768, need, s>>>(p);
+        }
+        return hipGetLastError();
+    }
+    if (npieces > 44) {
+        e = opt_in_lds(reinterpret_cast<const void*>(&conv_patch_kernel<HT, TN, 13>), 163840);
+        if (e != hipSuccess) return e;
+        conv_patch_kernel<HT, TN, 13><<<grid, 768, need, s>>>(p);
+    } else {
+        e = opt_in_lds(reinterpret_cast<const void*>(&conv_patch_kernel<HT, TN, 11>), 163840);
+        if (e != hipSuccess) return e;
+        conv_patch_kernel<HT, TN, 11><<<grid, 768, need, s>>>(p);
+    }
     return hipGetLastError();
 }
 
@@ -1778,6 +2318,12 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
         else if (pl.bm == 64 && pl.bn == 160) e = launch_lc<HT, CONV, 2, 5>(p, gz, s);
         else if (pl.bm == 64 && pl.bn == 128) e = launch_lc<HT, CONV, 2, 4>(p, gz, s);
         else { gmd_set_error("%s: loader/consumer tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
+        done = true;
+    } else if (CONV && pl.pf == 283 && g_conv_patch_mode != 0 && conv_patch_ok(p) && (int64_t)pl.ksplit <= p.Cin / BK) {
+        // ping-pong structure with the input patch resident in LDS (conv_patch_kernel): same tiles, same epilogues, same plan code
+        if (pl.bn == 160) e = launch_conv_patch<HT, 5>(p, gz, s);
+        else if (pl.bn == 128) e = launch_conv_patch<HT, 4>(p, gz, s);
+        else { gmd_set_error("%s: ping-pong tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
         done = true;
     } else if (pl.pf == 283) {  // ping-pong kernel: 8 consumer + 4 loader waves on a 256-row tile
         if (pl.bm == 256 && pl.bn == 160) e = launch_pp<HT, CONV, 5>(p, gz, s);
@@ -1864,6 +2410,16 @@ int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit) {
         return GMD_ERR_UNSUPPORTED;
     }
     g_force.bm = bm; g_force.bn = bn; g_force.pf = pf; g_force.ks = ksplit;
+    return GMD_OK;
+}
+
+int gmd_conv_patch_override(int mode) {
+    GMD_REQUIRE(mode >= 0 && mode <= 2, "gmd_conv_patch_override: mode 0, 1 or 2");
+    if (!tuning_enabled()) {
+        gmd_set_error("gmd_conv_patch_override: kernel-tuning overrides are a debug facility; set GMD_TUNING=1 in the environment to use them");
+        return GMD_ERR_UNSUPPORTED;
+    }
+    g_conv_patch_mode = mode;
     return GMD_OK;
 }
 

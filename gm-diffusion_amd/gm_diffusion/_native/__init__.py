@@ -45,6 +45,8 @@ SIGNATURES = {
     "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, I, P, L, P],
     "gmd_gemm_colstats_plan": [I, I, I, I, I, L, I],
     "gmd_gemm_plan_info": [I, I, I, I, I, L, I, P],
+    "gmd_conv_patch_override": [I],
+    "gmd_stamp": [P, P, I, I, P],
     "gmd_split_weights": [P, P, L, L, L, P],
     "gmd_ff_geglu_fused_supported": [I, L, I],
     "gmd_ff_geglu_fused": [P, P, P, P, P, P, P, I, L, I, P],

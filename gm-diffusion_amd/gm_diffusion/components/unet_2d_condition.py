@@ -651,6 +651,8 @@ class UNet2DConditionModel(_HipModule):
         so the host can run ahead of the GPU)."""
         self._ensure()
         self._t_dev.copy_(ts_dev[i:i + 1], non_blocking=True)
+        if getattr(self, "_stamp_buf", None) is not None:  # measurement hook: this iteration's row of the stamp table
+            self._stamp_row.fill_(i)
 
     def supports_cfg_shared(self):
         """True when the first down block has a transformer (SD-1.5): the prefix shared by a CFG pair ends at its
@@ -719,6 +721,17 @@ class UNet2DConditionModel(_HipModule):
         c = self.config
         eps = c.norm_eps
         ehs = encoder_hidden_states
+        # measurement hook (tools/timeline.py): device-time stamps at the block boundaries of this forward, into
+        # self._stamp_buf[self._stamp_row[0], k]; None in every normal run
+        sb = getattr(self, "_stamp_buf", None)
+        sk = [0]
+
+        def mark():
+            if sb is not None:
+                ops.stamp(sb, sk[0], self._stamp_row)
+                sk[0] += 1
+
+        mark()
         if ehs.dtype != self._dtype:
             raise HipExtensionError("encoder_hidden_states must already be in the UNet dtype (use prepare_context)")
         if cfg_shared and (B % 2 or not self.supports_cfg_shared()):
@@ -750,9 +763,11 @@ class UNet2DConditionModel(_HipModule):
                 x, H, W = ops.conv3x3(x, blk["ds"][0], B, H, W, bias=blk["ds"][1], stride=2,
                                       colstats=self._wants_colstats(H // 2, W // 2))
                 skips.append((x, H, W))
+            mark()  # end of a down block
         x = self._resnet(w["mid"]["r0"], x, B, H, W, temb, eps)
         x = self._transformer(w["mid"]["a"], x, B, H, W, ehs)
         x = self._resnet(w["mid"]["r1"], x, B, H, W, temb, eps)
+        mark()  # end of the mid block
         for blk in w["up"]:
             for j, r in enumerate(blk["res"]):
                 s, _, _ = skips.pop()
@@ -762,9 +777,12 @@ class UNet2DConditionModel(_HipModule):
             if "us" in blk:
                 x, H, W = ops.conv3x3(x, blk["us"][0], B, H, W, bias=blk["us"][1], upsample=True,
                                       colstats=self._wants_colstats(2 * H, 2 * W))
+            mark()  # end of an up block
         x = ops.groupnorm(x, B, c.norm_num_groups, w["norm_out"][0], w["norm_out"][1], eps, silu=True)
         y, _, _ = ops.conv3x3(x, w["conv_out"][0], B, H, W, bias=w["conv_out"][1], out_dtype=torch.float32)
-        return ops.unpack_nchw(y, B, c.out_channels, H, W)
+        out = ops.unpack_nchw(y, B, c.out_channels, H, W)
+        mark()  # end of the forward
+        return out
 
     @_in_own_f32_mode
     def graphed_forward(self, B, H, W, ehs, cfg_shared=False):

@@ -253,6 +253,13 @@ def gemm_plan_info(dtype, M, N, K, batch=1, geglu=False):
     return tuple(out)
 
 
+def stamp(buf, k, row=None):
+    """Measurement only: write the device's 100 MHz counter into ``buf[row[0], k]`` (``buf``: int64 [rows, stride] device tensor,
+    ``row``: int32 device scalar or None = row 0) at this point of the current stream -- also inside a graph capture (gmd_stamp)."""
+    stride = buf.shape[-1] if buf.dim() == 2 else 0
+    check(lib().gmd_stamp(buf.data_ptr(), _ptr(row), stride, int(k), _stream()), "gmd_stamp")
+
+
 def carry_colstats(dst, src):
     """``dst`` is a view of ``src`` with the same rows x channels content: keep the producer statistics attached."""
     st = getattr(src, "_colstats", None)

@@ -228,6 +228,18 @@ int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t wo
  * it to know what they exercise; nothing in the product path calls it.  Returns GMD_ERR_INVALID for other element types. */
 int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4);
 
+/* Debug facility like gmd_gemm_plan_override (refused unless the process has GMD_TUNING=1): how stride-1 gmd_conv3x3 launches on
+ * 256-row ping-pong tiles fetch their activations -- 2 (the default) = the tile's input patch resident in LDS, continuous consumers;
+ * 1 = patch resident, ping-pong consumers; 0 = the per-tap implicit GEMM.  Results agree to rounding (the K order differs).  Seeded
+ * from GMD_CONV_PATCH when the library is loaded. */
+int gmd_conv_patch_override(int mode);
+
+/* Measurement only: a one-thread kernel that writes the device's constant-rate 100 MHz counter into base[*row * stride + k] (device
+ * memory; `row` may be NULL = row 0) at its place in `stream` -- also inside a captured HIP graph, where `row` (a device scalar the host
+ * rewrites between replays) lets every replay fill its own row.  tools/timeline.py places such stamps at the block boundaries of both
+ * UNet forwards to record the concurrent timeline of the two-stream pipeline. */
+int gmd_stamp(uint64_t* base, const int* row, int stride, int k, gmd_stream_t stream);
+
 /* GEGLU feed-forward of a BasicTransformerBlock in ONE launch (diffusers FeedForward: ff.net.0 = GEGLU(C -> 4C), ff.net.2 =
  * Linear(4C -> C); the reference reaches it through UNet2DConditionModel at stable_diffusion_dual_unet.py:1052, 1083):
  *   Y = (value * gelu_erf(gate)) @ W2^T + b2 + residual,  [value | gate] = X @ W1i^T + b1i

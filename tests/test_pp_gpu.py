@@ -25,6 +25,7 @@ def force_plan():
 
     yield force
     lib().gmd_gemm_plan_override(0, 0, 0, 0)
+    lib().gmd_conv_patch_override(2)
     if prev is None:
         os.environ.pop("GMD_TUNING", None)
     else:
@@ -56,26 +57,66 @@ def _conv_ref(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, u
 
 
 @pytest.mark.parametrize("M,N,K,geglu,expect", [
-    (32768, 320, 320, False, (256, 160, 283, 1)),    # level-0 projections at batch 8
-    (32768, 320, 1280, False, (256, 160, 283, 1)),   # level-0 ff2
+    (32768, 320, 320, False, (256, 160, 283, 1)),    # level-0 projections at batch 8: 256 ping-pong tiles
+    (32768, 320, 2880, False, (256, 160, 283, 1)),   # level-0 convolutions at batch 8
     (8192, 1280, 640, False, (256, 160, 283, 1)),    # level-1 fused qk
-    (8192, 640, 11520, False, (256, 160, 283, 2)),   # conv 32x32 1280->640 at batch 8: two K slices
-    (16384, 320, 8640, False, (256, 160, 283, 2)),   # conv 64x64 960->320 at batch 4
-    (2048, 10240, 1280, True, (256, 128, 283, 1)),   # level-2 GEGLU projection
-    (8192, 5120, 640, True, (256, 128, 283, 1)),
     (131072, 512, 4608, False, (256, 128, 283, 1)),  # VAE decoder 128x128 512->512 at batch 8
+    (2048, 10240, 1280, True, (256, 128, 283, 1)),   # GEGLU projections from K = 1280 up
+    (8192, 5120, 640, True, (256, 128, 283, 1)),
+    (16384, 320, 2880, False, (128, 160, 244, 1)),   # level-0 convolutions at batch 4: 256 tiles of 128 x 160, one per CU
+    (8192, 640, 5760, False, (128, 160, 244, 1)),    # level-1 convolutions at batch 8
+    (4096, 640, 5760, False, (64, 160, 244, 1)),     # ... at batch 4: 64-row tiles
+    (2048, 1280, 1280, False, (64, 160, 244, 1)),    # level-2 projections at batch 8
+    (2048, 1280, 11520, False, (128, 160, 244, 2)),  # level-2 convolutions: deep K -> two slices of 128-row tiles beat 64-row tiles
+    (1024, 1280, 5120, False, (128, 160, 244, 4)),   # feed-forward output at batch 4, level 2
+    (512, 1280, 11520, False, (128, 160, 244, 7)),   # 8x8 convolutions at batch 8: 32 tiles x 7 slices
 ])
-def test_heuristic_hands_these_launches_to_the_ping_pong_kernel(M, N, K, geglu, expect):
+def test_default_policy_picks_the_fastest_plan_launch_by_launch(M, N, K, geglu, expect):
+    """make_plan's default rules (csrc/gemm.hip): ping-pong tiles where >= 256 of them exist, the loader/consumer kernel at about
+    one tile per CU (tools/sweep_pp.py, sweep_lc.py, check_ring.py)."""
     from gm_diffusion import hip_ops as ops
 
     assert ops.gemm_plan_info(torch.bfloat16, M, N, K, 1, geglu) == expect
 
 
-@pytest.mark.parametrize("M,N,K,geglu", [(4096, 640, 640, False), (512, 1280, 1280, False), (16384, 2560, 320, True), (2048, 1280, 5120, False)])
-def test_heuristic_keeps_the_ring_kernels_elsewhere(M, N, K, geglu):
+@pytest.mark.parametrize("M,N,K,geglu", [(1024, 1280, 1280, False), (512, 1280, 1280, False), (16384, 2560, 320, True), (4096, 200, 640, False)])
+def test_default_policy_keeps_the_ring_kernels_elsewhere(M, N, K, geglu):
     from gm_diffusion import hip_ops as ops
 
     assert ops.gemm_plan_info(torch.bfloat16, M, N, K, 1, geglu)[2] == 0
+
+
+@pytest.mark.parametrize("bm,bn,ks,M,N,K", [(128, 160, 1, 8192, 640, 640), (64, 160, 1, 2048, 1280, 1280), (128, 128, 2, 1000, 384, 1280),
+                                            (64, 128, 3, 520, 256, 1920), (128, 160, 4, 1024, 1280, 5120)])
+def test_lc_kernel_vs_float64(bm, bn, ks, M, N, K, force_plan):
+    """gemm_lc_kernel (plan code 244; selected by GMD_PP=i, the launch-by-launch rules): 4 consumer waves with double-buffered
+    fragments + 4 loader waves, 4-stage ring.  Full and ragged tiles, K slices, residual."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    force_plan(bm, bn, 244, ks)
+    y = ops.gemm_nt(a, w, bias=b, residual=r)
+    assert _rel(y, a.double() @ w.double().T + b.double() + r.double()) < 4e-3
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stride=2), dict(upsample=True)])
+def test_lc_kernel_conv3x3_vs_float64(kw, force_plan):
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(len(kw) + 21)
+    B, H, W, ci, co = 3, 24, 20, 128, 320
+    x = torch.randn(B, H * W, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.03).bfloat16().to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    tb = torch.randn(B, co, generator=g).to(DEV)
+    for bm in (128, 64):
+        force_plan(bm, 160, 244, 1)
+        y, _, _ = ops.conv3x3(x, w, B, H, W, bias=b, rowbias=tb, **kw)
+        assert _rel(y, _conv_ref(x, w, B, H, W, bias=b, rowbias=tb, **kw)) < 4e-3
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-3), (torch.float16, 5e-4)])
@@ -198,3 +239,65 @@ def test_pp_column_statistics_feed_groupnorm(force_plan):
     y_plain = y.clone()                                                  # no statistics attached: two-launch path
     bref = ops.groupnorm(y_plain, B, 32, ga, be, 1e-5, silu=True)
     assert float((a.float() - bref.float()).abs().max()) <= 2 ** -6
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,ks", [
+    (2, 64, 64, 128, 320, 1),    # 4 image rows per tile, 6 x 66-pixel patch (NPP = 13), two 64-channel blocks (patch double buffer)
+    (1, 64, 64, 64, 160, 1),     # a single block: no next patch
+    (3, 32, 32, 192, 320, 1),    # 8 rows per tile, 10 x 34 patch (NPP = 11), three blocks
+    (3, 16, 16, 320, 128, 1),    # one image per tile, 18 x 18 patch; 256 x 128 tile
+    (6, 8, 8, 128, 320, 1),      # four images per tile (4 x 10 x 10 = 400 pixels); the second tile is half empty (M = 384)
+    (8, 8, 8, 320, 160, 2),      # K slices in whole 64-channel blocks: 5 blocks over 2 slices (3 + 2)
+    (2, 32, 32, 320, 320, 5),    # one block per slice
+    (4, 64, 32, 128, 160, 1),    # H != W
+])
+@pytest.mark.parametrize("mode", [2, 1])
+def test_conv_patch_kernel_vs_float64(B, H, W, ci, co, ks, mode, force_plan):
+    """conv_patch_kernel: the input patch of a 256-pixel tile (+ halo) resident in LDS, nine taps read it at shifted rows.  Every
+    geometry class of its tile -> patch mapping, with bias, per-sample row bias and residual, against the float64 convolution;
+    and bit-identical to the per-tap implicit GEMM of gemm_pp_kernel (same tiles, same K order within a tap? no: the K order
+    differs -- channel block outer -- so the comparison is to rounding)."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(B * 1000 + H + ci)
+    x = torch.randn(B, H * W, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.03).bfloat16().to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    tb = torch.randn(B, co, generator=g).to(DEV)
+    r = torch.randn(B, H * W, co, generator=g).bfloat16().to(DEV)
+    from gm_diffusion._native import lib
+
+    force_plan(256, 160 if co % 160 == 0 else 128, 283, ks)
+    assert lib().gmd_conv_patch_override(mode) == 0  # 2: continuous consumers (the default), 1: ping-pong consumers
+    y, ho, wo = ops.conv3x3(x, w, B, H, W, bias=b, rowbias=tb, residual=r)
+    ref = _conv_ref(x, w, B, H, W, bias=b, rowbias=tb, residual=r)
+    assert (ho, wo) == (H, W) and _rel(y, ref) < 4e-3
+    # the same launch through the per-tap implicit GEMM of gemm_pp_kernel: same tiles, another K order
+    assert lib().gmd_conv_patch_override(0) == 0
+    y2, _, _ = ops.conv3x3(x, w, B, H, W, bias=b, rowbias=tb, residual=r)
+    assert float((y.float() - y2.float()).abs().max()) <= 4 * float(ref.abs().max()) * 2 ** -8
+
+
+def test_conv_patch_kernel_f16_and_column_statistics(force_plan):
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(77)
+    B, H, ci, co = 4, 32, 128, 320
+    x = torch.randn(B, H * H, ci, generator=g).half().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.03).half().to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    force_plan(256, 160, 283, 1)
+    y, _, _ = ops.conv3x3(x, w, B, H, H, bias=b)
+    assert _rel(y, _conv_ref(x, w, B, H, H, bias=b)) < 5e-4
+    from gm_diffusion._native import lib
+    lib().gmd_gemm_plan_override(0, 0, 0, 0)
+    # heuristic path with producer statistics (M = 32768 at 64x64 x 8: ping-pong tiles, unsplit)
+    B, H, ci, co = 8, 64, 64, 320
+    x = torch.randn(B, H * H, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.03).bfloat16().to(DEV)
+    assert ops.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci) == (256, 160, 283, 1)
+    y, _, _ = ops.conv3x3(x, w, B, H, H, bias=b, colstats=True)
+    st, _ = y._colstats
+    yd = y.double().view(B * H * H // 64, 64, co // ops.COLSTATS_BUCKET, ops.COLSTATS_BUCKET)
+    assert float((st[..., 0].double().cpu() - yd.sum((1, 3)).cpu()).abs().max()) < 2e-3
+    assert _rel(y, _conv_ref(x, w, B, H, H, bias=b)) < 4e-3

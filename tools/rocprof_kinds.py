@@ -24,7 +24,9 @@ for s, e, name in rows:
             agg[last_kind][1] += d
         continue
     # <[element type, ]CONV, ...> for the 16-bit kernels, <CONV, ...> for the float32 ones
-    g = re.search(r"gemm_(?:split|f32)_kernel<(true|false)", name) or re.search(r"gemm_(?:ring|bf16)_kernel<[^,<>]+, (true|false)", name)
+    g = re.search(r"gemm_(?:split|f32)_kernel<(true|false)", name) or re.search(r"gemm_(?:ring|bf16|pp|lc)_kernel<[^,<>]+, (true|false)", name)
+    if g is None and "conv_patch" in name:  # round 4: conv3x3 with the input patch resident in LDS
+        g = re.match(r"(true)", "true")
     # arithmetic family: the default bench command also runs the float32 pipelines (tolerance_path, drift reference), whose
     # launches must not be averaged into the 16-bit kinds
     fam = (" [f32 split]" if ("gemm_split_kernel" in name or "attn_split_kernel" in name) else " [f32 exact]" if "gemm_f32_kernel" in name
