@@ -23,6 +23,7 @@
 int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
 int gmd_launch_split_conv(const void* params, int w_presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
 int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes);
+int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int bucket);
 
 namespace {
 
@@ -2424,6 +2425,7 @@ int gmd_conv_patch_override(int mode) {
 }
 
 int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket) {
+    if (dtype == GMD_F32S || dtype == GMD_F32SW) return gmd_split_colstats_ok(M, N, K, batch, workspace_bytes, bucket);  // round 4
     if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 0;
     return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false), M, N, batch, bucket) ? 1 : 0;
 }
@@ -2477,7 +2479,6 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     p.cblk = K;
     p.colstats = colstats; p.cs_bucket = colstats_bucket;
     if (split) {
-        GMD_REQUIRE(!colstats, "gmd_gemm_nt: column statistics are implemented for the 16-bit types only");
         return gmd_launch_split_gemm(&p, dtype == GMD_F32SW, batch, batch == 1 ? workspace : nullptr, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
     }
     return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");

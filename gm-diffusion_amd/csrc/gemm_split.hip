@@ -174,6 +174,7 @@ __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32
         grem = mw - g0 * p.rows_per_group;
     }
     float* slab = SLAB ? p.ws + (int64_t)ks * p.M * p.N : nullptr;
+    float cs[(NCOL + 63) / 64] = {}, cq[(NCOL + 63) / 64] = {};  // column sums of this wave tile (p.colstats only; round 4)
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
@@ -214,8 +215,51 @@ __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs_f32
             *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.colstats)  // the stored values go back to the strip for the column pass below
+                *reinterpret_cast<float4*>(strip + r * ROWF + c * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
         __builtin_amdgcn_wave_barrier();
+        if (!SLAB && p.colstats) {  // lane -> column (and column 64 + lane): 32 conflict-free reads each, fixed order
+#pragma unroll
+            for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+                const int cc = lane + 64 * k;
+                if (cc < NCOL) {
+                    float s_ = 0.f, q_ = 0.f;
+#pragma unroll 8
+                    for (int r = 0; r < 32; ++r) {
+                        const float x = strip[r * ROWF + cc];
+                        s_ += x;
+                        q_ += x * x;
+                    }
+                    cs[k] += s_;
+                    cq[k] += q_;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // producer statistics for a following GroupNorm, the layout of the 16-bit kernels (gemm.hip: epilogue_rows): {sum, sum of
+    // squares} of the STORED values over this wave tile's 64 rows and each bucket of cs_bucket adjacent columns
+    if (!SLAB && p.colstats) {
+#pragma unroll
+        for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+            const int cc = lane + 64 * k;
+            if (cc < NCOL) {
+                strip[cc] = cs[k];
+                strip[ROWF + cc] = cq[k];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nb = NCOL / p.cs_bucket;
+        if (lane < nb) {
+            float s_ = 0.f, q_ = 0.f;
+            for (int e = 0; e < p.cs_bucket; ++e) {
+                s_ += strip[lane * p.cs_bucket + e];
+                q_ += strip[ROWF + lane * p.cs_bucket + e];
+            }
+            float* o = p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket + lane) * 2;
+            *reinterpret_cast<float2*>(o) = make_float2(s_, q_);
+        }
     }
 }
 
@@ -556,6 +600,9 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 struct SplitPlan {
     int bm, bn, ksplit;
 };
+}  // namespace
+int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int bucket);
+namespace {
 
 // Tile / split-K selection: the 16-bit heuristic of gemm.hip (make_plan) in units of 64-deep K steps; the tiles are
 // 128 x 160 / 128 x 128 (two workgroups per CU) and 64 x 64 for launches that cannot put 256 large tiles on the chip.
@@ -601,6 +648,15 @@ int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStr
         if (pl.bn == 160) pl.bn = 128;
         pl.ksplit = 1;
     }
+    if (p.colstats) {
+        const bool rows_ok = p.act != GMD_ACT_GEGLU && (p.ldc & 3) == 0 && (p.residual == nullptr || (p.ldr & 3) == 0) &&
+                             (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0));
+        if (!rows_ok || !gmd_split_colstats_ok(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.cs_bucket)) {
+            gmd_set_error("%s: this float32 launch cannot emit column statistics (full-tile row epilogue of an unsplit 128-row launch: ask "
+                          "gmd_gemm_colstats_plan first)", name);
+            return GMD_ERR_UNSUPPORTED;
+        }
+    }
     p.ksplit = pl.ksplit;
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
@@ -637,6 +693,14 @@ int split_channel_block(int B, int Hin, int Win, int Cin, int Cout) {
 }
 
 }  // namespace
+
+// producer column statistics (GemmParams::colstats) come out of the full-tile row epilogue of an unsplit launch of the 128-row
+// kernels, whose waves own 64 rows x (BN/2) columns -- a whole number of buckets: the float32 twin of colstats_plan_ok (gemm.hip)
+int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int bucket) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 || batch != 1 || bucket <= 0) return 0;
+    const SplitPlan pl = make_split_plan(M, N, K, batch, ws_bytes);
+    return (pl.bm == 128 && pl.ksplit == 1 && M % 128 == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0) ? 1 : 0;
+}
 
 // split-K factor launch_split_any will choose (no GEGLU): gmd_conv3x3_groupnorm / gmd_conv3x3_gn_fusable of gemm.hip
 int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes) { return make_split_plan(M, N, K, 1, ws_bytes).ksplit; }

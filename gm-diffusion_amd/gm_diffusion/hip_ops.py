@@ -235,10 +235,16 @@ USE_COLSTATS = os.environ.get("GMD_COLSTATS", "1") != "0"  # A/B switch (tests, 
 colstats_uses = 0     # GroupNorm calls served from producer statistics (tests assert the path is really taken)
 
 
-def _colstats_buffer(want, dtype, M, N, K, batch, out_dtype, device):
-    if not want or not USE_COLSTATS or not is_half(dtype) or out_dtype != dtype or M % 64 or N % COLSTATS_BUCKET:
+def _colstats_buffer(want, dtype, M, N, K, batch, out_dtype, device, code=None):
+    """Buffer for the producer's column statistics when this launch can emit them: the 16-bit types, and (round 4) float32 on the
+    matrix cores -- ``code`` is the launch's dtype code (GMD_F32S / GMD_F32SW there)."""
+    if not want or not USE_COLSTATS or out_dtype != dtype or M % 64 or N % COLSTATS_BUCKET:
         return None
-    if not lib().gmd_gemm_colstats_plan(dtype_code(dtype), M, N, K, batch, WORKSPACE_BYTES, COLSTATS_BUCKET):
+    if is_half(dtype):
+        code = dtype_code(dtype)
+    elif code not in (GMD_F32S, GMD_F32SW):
+        return None
+    if not lib().gmd_gemm_colstats_plan(code, M, N, K, batch, WORKSPACE_BYTES, COLSTATS_BUCKET):
         return None
     return torch.empty((M // 64, N // COLSTATS_BUCKET, 2), dtype=torch.float32, device=device)
 
@@ -306,7 +312,7 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     ws = _workspace(a.device) if batch == 1 else None
     st = None
     if colstats and batch == 1 and a.dim() == 2 and w.dim() == 2 and act != ACT_GEGLU and ldc == N:
-        st = _colstats_buffer(True, a.dtype, M, N, K, 1, out_dtype, a.device)
+        st = _colstats_buffer(True, a.dtype, M, N, K, 1, out_dtype, a.device, code=dt)
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("gemm_nt") else None
     t0 = tm.begin() if tm else None
@@ -376,7 +382,7 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     if rowbias is not None and (rowbias[0] if isinstance(rowbias, tuple) else rowbias).shape[0] != B:
         raise HipExtensionError("conv3x3: rowbias must have one row per sample")
     ws = _workspace(x.device)
-    st = _colstats_buffer(colstats, x.dtype, B * ho * wo, cout, 9 * cin, 1, out_dtype, x.device)
+    st = _colstats_buffer(colstats, x.dtype, B * ho * wo, cout, 9 * cin, 1, out_dtype, x.device, code=_contract_code(x, w, cin))
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("conv3x3") else None
     t0 = tm.begin() if tm else None

@@ -467,3 +467,41 @@ def test_module_keeps_the_f32_mode_it_was_prepared_for():
             assert torch.equal(a, b) and torch.equal(da, db), own
         finally:
             o.set_f32_mode(prev)
+
+
+@pytest.mark.parametrize("B,H,ci,co", [(8, 32, 64, 640), (4, 64, 32, 320), (2, 64, 64, 256)])
+def test_split_kernels_emit_producer_statistics_for_groupnorm(B, H, ci, co):
+    """Round 4: the float32 matrix-core kernels emit the GroupNorm column statistics out of their row epilogue like the 16-bit
+    kernels (float32 GroupNorm then reads its tensor once): sums of the STORED values per 64 rows x 10 channels against float64,
+    and GroupNorm from them against the statistics-launch path on the same tensor."""
+    o = ops()
+    g = torch.Generator().manual_seed(B + H + co)
+    x = torch.randn(B, H * H, ci, generator=g).to(DEV)
+    w = o.split_weights((torch.randn(co, 9 * ci, generator=g) * 0.05).to(DEV))
+    b = torch.randn(co, generator=g).to(DEV)
+    tb = torch.randn(B, co, generator=g).to(DEV)
+    prev = o.set_f32_mode("split")
+    try:
+        y, _, _ = o.conv3x3(x, w, B, H, H, bias=b, rowbias=tb, colstats=True)
+        if co % o.COLSTATS_BUCKET:  # 256 channels: no whole number of 10-channel buckets -> no statistics, the plain paths
+            assert getattr(y, "_colstats", None) is None
+            ga, be = torch.randn(co, generator=g).to(DEV), torch.randn(co, generator=g).to(DEV)
+            ref = F.silu(F.group_norm(y.double().view(B, H * H, co).permute(0, 2, 1), 32, ga.double(), be.double(), 1e-5)).permute(0, 2, 1)
+            assert rel_err(o.groupnorm(y, B, 32, ga, be, 1e-5, silu=True), ref) < 2e-6
+            return
+        assert getattr(y, "_colstats", None) is not None, "the launch must take the statistics path"
+        st, _ = y._colstats
+        if True:
+            yd = y.double().view(B * H * H // 64, 64, co // o.COLSTATS_BUCKET, o.COLSTATS_BUCKET)
+            s1, s2 = yd.sum((1, 3)), (yd * yd).sum((1, 3))
+            assert float((st[..., 0].double() - s1).abs().max()) < 1e-3 * float(s1.abs().max() + 1)
+            assert float(((st[..., 1].double() - s2).abs() / s2).max()) < 1e-5
+        ga, be = torch.randn(co, generator=g).to(DEV), torch.randn(co, generator=g).to(DEV)
+        before = o.colstats_uses
+        a = o.groupnorm(y, B, 32, ga, be, 1e-5, silu=True)
+        assert o.colstats_uses == before + 1
+        bref = o.groupnorm(y.clone(), B, 32, ga, be, 1e-5, silu=True)  # no statistics attached: statistics launch
+        ref = F.silu(F.group_norm(y.double().view(B, H * H, co).permute(0, 2, 1), 32, ga.double(), be.double(), 1e-5)).permute(0, 2, 1)
+        assert rel_err(a, ref) < 2e-6 and rel_err(bref, ref) < 2e-6
+    finally:
+        o.set_f32_mode(prev)
