@@ -48,7 +48,7 @@ KIND_KERNEL = {
     "concat": "gmd_concat_channels (skip connections)",
     "hdr_tail": "gmd_hdr_tail (denorm/clamp + u8 + Eq. 1 + /(qmax+1) + u16)",
 }
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def parse():

@@ -933,10 +933,11 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
         const int nwg = gridDim.x, id = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        const int tiles_n = (p.N + BN - 1) / BN;
-        const int mt = L / tiles_n;
+        const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+        int mt, nt;
+        grouped_tile(L, tiles_m, tiles_n, p.tile_group, mt, nt);
         m0 = mt * BM;
-        n0 = (L - mt * tiles_n) * BN;
+        n0 = nt * BN;
     }
     const int z = p.ksplit > 1 ? 0 : blockIdx.z;
     const int ks = p.ksplit > 1 ? blockIdx.z : 0;
@@ -1251,15 +1252,10 @@ __global__ __launch_bounds__(512, 2) void gemm_lc_kernel(const GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
         const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-        if (p.M >= p.N) {  // n-fastest: an XCD's run of tiles shares its A row panels
-            const int mt = L / tiles_n;
-            m0 = mt * BM;
-            n0 = (L - mt * tiles_n) * BN;
-        } else {           // small-M launches: the weight panel is the larger operand
-            const int nt = L / tiles_m;
-            n0 = nt * BN;
-            m0 = (L - nt * tiles_m) * BM;
-        }
+        int mt, nt;
+        grouped_tile(L, tiles_m, tiles_n, p.tile_group, mt, nt);  // (tile_group = tiles_m: m fastest, for W-heavy launches)
+        m0 = mt * BM;
+        n0 = nt * BN;
     }
     const int z = p.ksplit > 1 ? 0 : blockIdx.z;
     const int ks = p.ksplit > 1 ? blockIdx.z : 0;
@@ -2300,6 +2296,25 @@ const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch) {
     return nullptr;
 }
 
+// Tile order of the ping-pong / loader-consumer kernels (GemmParams::tile_group).  Workgroups with equal id % 8 share an XCD and get
+// a contiguous run of tiles; with n fastest an XCD walks whole M-panels, so between two uses of a weight tile lie all the others:
+//   * weights larger than the activations (N > M: the GEGLU projections of the 16x16 / 8x8 levels, W up to 26 MB): m fastest --
+//     each weight tile then goes to ONE XCD instead of all eight (rocprofv3 FETCH_SIZE, M=2048 N=10240 K=1280: 226 MB = 7.2x the
+//     algorithmic reads with n fastest);
+//   * activations larger, but the weights do not fit an XCD's 4 MiB L2 beside them (M=8192 N=5120 K=640: W = 6.5 MB, 231 MB fetched
+//     = 13.6x): the XCD's M-panels are walked together, one N tile at a time, so every weight tile is fetched once per XCD.
+// Everything else keeps n fastest.
+int pick_tile_group(const Plan& pl, int M, int N, int K) {
+    if (pl.pf != 283 && pl.pf != 244) return 1;
+    const int tiles_m = (M + pl.bm - 1) / pl.bm;
+    if (N > M) return tiles_m;
+    const int64_t w_bytes = (int64_t)N * K * 2;
+    if (w_bytes <= (3ll << 20)) return 1;
+    int g = (tiles_m + 7) / 8;  // the XCD's share of M-panels
+    if (g > 8) g = 8;
+    return g < 1 ? 1 : g;
+}
+
 template <typename HT, bool CONV>
 int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     constexpr bool kTune = std::is_same<HT, bf16_t>::value;
@@ -2311,6 +2326,7 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
     }
     p.ksplit = pl.ksplit;
     p.ws = (float*)ws;
+    p.tile_group = CONV ? 1 : pick_tile_group(pl, p.M, p.N, p.K);  // (convolutions: neighbouring M-panels share their halo rows)
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
     bool done = false;
     if (pl.pf == 244) {  // loader / consumer kernel: 4 consumer + 4 loader waves, 4-stage ring, one workgroup per CU

@@ -37,7 +37,26 @@ struct GemmParams {
     // split-K only: leave the partial slabs in `ws` and do NOT launch the reduction (the consumer sums them:
     // gmd_conv3x3_groupnorm -> gn_slab_kernel of norm.hip)
     int defer_reduce;
+    // tile order of the round-4 kernels inside an XCD's contiguous run of tiles: M-panels are walked in groups of `tile_group`
+    // (m fastest inside a group, then the next N tile, then the next group); 1 = n fastest (the ring kernels' order).  Chosen on
+    // the host so that what an XCD re-reads between reuses stays inside its 4 MiB L2 (gemm.hip: pick_tile_group).
+    int tile_group;
 };
+
+// (row tile, column tile) of linear tile index L under GemmParams::tile_group
+__device__ __forceinline__ void grouped_tile(int L, int tiles_m, int tiles_n, int group, int& mt, int& nt) {
+    if (group <= 1) {
+        mt = L / tiles_n;
+        nt = L - mt * tiles_n;
+        return;
+    }
+    const int gsz = group * tiles_n;
+    const int pg = L / gsz, r = L - pg * gsz;
+    const int left = tiles_m - pg * group;
+    const int rows = left < group ? left : group;  // the last group may be short
+    nt = r / rows;
+    mt = pg * group + (r - nt * rows);
+}
 
 // Row-invariant part of the A address of one staging slot.
 struct RowCtx {

@@ -301,3 +301,32 @@ def test_conv_patch_kernel_f16_and_column_statistics(force_plan):
     yd = y.double().view(B * H * H // 64, 64, co // ops.COLSTATS_BUCKET, ops.COLSTATS_BUCKET)
     assert float((st[..., 0].double().cpu() - yd.sum((1, 3)).cpu()).abs().max()) < 2e-3
     assert _rel(y, _conv_ref(x, w, B, H, H, bias=b)) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,geglu", [
+    (8192, 5120, 640, True),     # weights (6.5 MB) beyond an XCD's L2: M-panels walked in groups of 4, one N tile at a time
+    (2304, 5120, 640, False),    # 9 M-panels in groups of 2: the last group is short
+    (2048, 10240, 1280, True),   # N > M: m fastest (each weight tile goes to one XCD)
+    (600, 1280, 320, False),     # N > M with a ragged last M tile
+])
+def test_grouped_tile_orders_cover_every_tile_once(M, N, K, geglu, force_plan):
+    """The L2-aware tile orders of the round-4 kernels (GemmParams::tile_group) are pure permutations of the tile grid: results must
+    equal the float64 product whatever the order (a tile visited twice or never shows as a wrong or stale block)."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    for plan in ((256, 128, 283, 1), (128, 128, 244, 1)):
+        force_plan(*plan)
+        if geglu:
+            y = ops.gemm_nt(a, w, bias=b, act=ops.ACT_GEGLU).double().cpu()
+            h = a.double().cpu() @ w.double().cpu().T + b.double().cpu()
+            hv = h.view(M, N // 32, 2, 16)  # [16 value | 16 gate] column groups
+            ref = (hv[:, :, 0, :] * F.gelu(hv[:, :, 1, :])).reshape(M, N // 2)
+            assert y.shape == ref.shape and _rel(y, ref) < 8e-3
+        else:
+            y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm_nt(a, w, bias=b, out=y)
+            assert torch.isfinite(y).all() and _rel(y, a.double() @ w.double().T + b.double()) < 4e-3
