@@ -24,6 +24,7 @@ int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* w
 int gmd_launch_split_conv(const void* params, int w_presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
 int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes);
 int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int bucket);
+void gmd_split_set_lc(int mode);
 
 namespace {
 
@@ -2427,6 +2428,9 @@ int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit) {
         return GMD_ERR_UNSUPPORTED;
     }
     g_force.bm = bm; g_force.bn = bn; g_force.pf = pf; g_force.ks = ksplit;
+    // the float32 matrix-core path has its own planner (gemm_split.hip); of an override it takes the kernel family only:
+    // pf 244 = its loader / converter kernel wherever instantiated, anything else = its default (the in-register split)
+    gmd_split_set_lc(pf == 244 ? 1 : 0);
     return GMD_OK;
 }
 

@@ -580,6 +580,304 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
     epilogue_regs_f32<TM, TN>(p, acc, mw, nw, frow, fq, z, ks);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Loader / converter form (round 4): ONE workgroup per CU = 4 consumer waves (2 x 2, wave tile 64 x 16 TN) + 4 loader waves, tile
+// 128 x (32 TN), four 36 KB LDS stages, a K step of 32 elements, pre-split weights (GMD_F32SW) only.
+//
+// Why: in gemm_split_kernel above every wave issues its own LDS-DMA (an instruction that blocks while the CU's memory queue is full:
+// gemm.hip, gemm_pp_kernel), reads float32 fragments and splits them in registers -- 16 vector instructions per A fragment, done by
+// BOTH waves that share the fragment's rows, 2.4 VALU per MFMA in all (profiles/r03_pmc.txt) -- in front of the MFMAs that need them.
+// Here the loader waves own the DMA and, once a tile has landed, split its activation rows ONCE, IN PLACE, into the layout the
+// pre-split weights already have ([hi 64 B | lo 64 B] per 128-byte row: item (row, q) reads float32 chunks q and 4+q -- the k's lane
+// group q of a 16x16x32 MFMA consumes -- and writes the f16 hi halves back to chunk q, the lo halves to chunk 4+q).  The consumers
+// then read ready-made f16 fragments for both operands (18 ds_read_b128 per 60 MFMAs) and do nothing but multiply.
+//
+//   stage life: landing (DMA) -> converting (loaders, first half of the next K step) -> ready -> consumed -> free.  Per K step kt:
+//   loader:    convert tile kt+1 ; lgkmcnt(0) ; M(kt) ; issue tile kt+3 (stage of tile kt-1) ; vmcnt(tile kt+2 landed) ; B(kt+1)
+//   consumer:  first half of the MFMAs on tile kt ; M(kt) ; reads of tile kt+1 -> second fragment set ; second half ; B(kt+1)
+//   B(kt) guarantees: tile kt converted (M(kt-1)), tile kt+1 landed, every read of tile kt-1 returned (they were consumed).
+// The MFMA order per accumulator is gemm_split_kernel's (lo x hi, hi x lo, hi x hi per K step, K steps in the same order): results are
+// bit-identical to it.
+// ------------------------------------------------------------------------------------------------
+template <bool CONV, int TN>
+__global__ __launch_bounds__(512, 2) void gemm_split_lc_kernel(const GemmParams p) {
+    constexpr int WN = 2, NCONS = 4, LW = 4, NST = 4, TM = 4;
+    constexpr int BM = 2 * TM * 16, BN = WN * TN * 16;
+    constexpr int RPP = LW * 8;
+    constexpr int NA = BM / RPP, NW = BN / RPP, NP = NA + NW;
+    constexpr int NCV = BM * 4 / (LW * 64);          // conversion items (row, q) per loader lane and tile
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && (BM * 4) % (LW * 64) == 0, "tile rows must be whole staging passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kStage = (BM + BN) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wuni = __builtin_amdgcn_readfirstlane(wid);
+    const bool loader = wuni >= NCONS;
+    int m0, n0;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, j = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+        if (p.M >= p.N || CONV) {
+            const int mt = L / tiles_n;
+            m0 = mt * BM;
+            n0 = (L - mt * tiles_n) * BN;
+        } else {
+            const int nt = L / tiles_m;
+            n0 = nt * BN;
+            m0 = (L - nt * tiles_m) * BM;
+        }
+    }
+    const int z = 0;
+    const int ks = p.ksplit > 1 ? blockIdx.z : 0;
+    const int nk_total = p.K / BKS;
+    const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * per;
+    const int nk = (kt_begin + per <= nk_total ? per : nk_total - kt_begin);
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (loader) {
+        const int lw = wuni - NCONS;
+        const int ltid = tid - NCONS * 64;
+        const int srow = ltid >> 3;
+        const int chunk = (ltid & 7) ^ ((srow >> 1) & 7);
+        unsigned aoff[NA], woff[NW];
+        int pb[NA], py[NA], px[NA];
+        bool pv[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + srow + RPP * i;
+            pv[i] = m < p.M;
+            pb[i] = py[i] = px[i] = 0;
+            if (CONV) {
+                if (pv[i]) {
+                    const int hw = p.Hout * p.Wout;
+                    if (((hw & (hw - 1)) | (p.Wout & (p.Wout - 1))) == 0) {
+                        const int sh = __builtin_ctz(hw), sw = __builtin_ctz(p.Wout);
+                        pb[i] = m >> sh;
+                        const int rem = m & (hw - 1);
+                        py[i] = rem >> sw;
+                        px[i] = rem & (p.Wout - 1);
+                    } else {
+                        pb[i] = m / hw;
+                        const int rem = m - pb[i] * hw;
+                        py[i] = rem / p.Wout;
+                        px[i] = rem - py[i] * p.Wout;
+                    }
+                }
+                aoff[i] = kOOB;
+            } else {
+                aoff[i] = pv[i] ? (unsigned)m * (unsigned)p.lda * 4u + (unsigned)chunk * 16u : kOOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = n0 + srow + RPP * i;
+            woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 4u + (unsigned)chunk * 16u : kOOB;
+        }
+        int tap = 0, c0 = 0, cb0 = 0;
+        bool newtap = true;
+        if (CONV) {
+            const int sb = p.cblk / BKS, per_cb = 9 * sb;
+            const int cbi = kt_begin / per_cb, rem = kt_begin - cbi * per_cb;
+            tap = rem / sb;
+            cb0 = cbi * p.cblk;
+            c0 = cb0 + (rem - tap * sb) * BKS;
+        }
+        const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+        u32x4 dA, dW;
+        {
+            const uint64_t ba = (uint64_t)p.A, bw = (uint64_t)p.W;
+            dA = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.a_bytes), 0x00020000u};
+            dW = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bw), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bw >> 32) & 0xffffu),
+                       (unsigned)__builtin_amdgcn_readfirstlane(p.w_bytes), 0x00020000u};
+        }
+        auto dma16 = [&](const u32x4& desc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                         :
+                         : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+                         : "memory", "m0");
+#pragma clang diagnostic pop
+        };
+        // pieces [LO, HI) of one tile (A passes first, then W passes); LO == 0 opens the tile (conv: new tap offsets), HI == NP closes it
+        auto dma_part = [&](auto LO, auto HI, int kt, int stage_idx) {
+            constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+            unsigned kbytes = (unsigned)(kt_begin + kt) * (BKS * 4);
+            unsigned abytes = kbytes;
+            if (CONV) {
+                if (lo == 0 && newtap) {
+                    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) aoff[i] = conv_tap_offset_f32(p, pv[i], pb[i], py[i], px[i], ky, kx, chunk);
+                    newtap = false;
+                }
+                abytes = (unsigned)c0 * 4u;
+                kbytes = (unsigned)(tap * p.Cin + c0) * 4u;
+            }
+            const unsigned stage = lds_base + (unsigned)stage_idx * kStage + (unsigned)lw * (8 * 128);
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (i >= lo && i < hi) dma16(dA, stage + i * (RPP * 128), aoff[i], abytes);
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                if (NA + i >= lo && NA + i < hi) dma16(dW, stage + BM * 128 + i * (RPP * 128), woff[i], kbytes);
+            if (CONV && hi == NP) {
+                c0 += BKS;
+                if (c0 >= cb0 + p.cblk) {
+                    c0 = cb0;
+                    ++tap;
+                    newtap = true;
+                    if (tap == 9) { tap = 0; cb0 += p.cblk; c0 = cb0; }
+                }
+            }
+        };
+        auto dma_tile = [&](int kt, int stage_idx) { dma_part(IntC<0>{}, IntC<NP>{}, kt, stage_idx); };
+        // split the activation rows of one landed tile in place (this wave's share of the (row, q) items)
+        auto convert_item = [&](int stage_idx, int j) {
+            unsigned char* sA = smem + stage_idx * kStage;
+            {
+                const int id = ltid + (LW * 64) * j;
+                const int row = id >> 2, q = id & 3;
+                float4* p0 = reinterpret_cast<float4*>(sA + lds_off(row, q));
+                float4* p1 = reinterpret_cast<float4*>(sA + lds_off(row, 4 + q));
+                const float4 x0 = *p0, x1 = *p1;
+                uint4 hi, lo;
+                split8(x0, x1, hi, lo);
+                *reinterpret_cast<uint4*>(p0) = hi;
+                *reinterpret_cast<uint4*>(p1) = lo;
+            }
+        };
+        auto convert_tile = [&](int stage_idx) {
+#pragma unroll
+            for (int j = 0; j < NCV; ++j) convert_item(stage_idx, j);
+        };
+        if (nk > 0) {  // block-uniform
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (t < nk) dma_tile(t, t);
+            // tile 0 landed (at most tiles 1 and 2 outstanding); every loader's pieces: barrier; convert tile 0; barrier
+            if (nk >= 3) wait_vmcnt<2 * NP>();
+            else if (nk == 2) wait_vmcnt<NP>();
+            else wait_vmcnt<0>();
+            seg_barrier();          // P0: tile 0 has landed
+            convert_tile(0);
+            // tile 1 has landed too before B(0) (it is converted during K step 0)
+            if (nk >= 3) wait_vmcnt<NP>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            seg_barrier();          // B(0): tile 0 ready, tile 1 landed
+            int st_fill = 3;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int st_next = (kt + 1) & 3;
+                const bool more = kt + 3 < nk;
+                // The A pieces of tile kt+3 (its stage was freed by B(kt)) go out BETWEEN the conversion items of tile kt+1: an LDS-DMA
+                // issued into a full memory queue blocks the wave, a queue that is fed one piece per ~100 cycles does not, and the
+                // split's VALU / LDS work fills the gaps (issued back to back in front of the conversion the K step took 2000 cycles)
+                static_assert(NCV == 2 && NA == 4, "interleave below");
+                if (more) dma_part(IntC<0>{}, IntC<1>{}, kt + 3, st_fill);
+                if (kt + 1 < nk) convert_item(st_next, 0);
+                if (more) dma_part(IntC<1>{}, IntC<3>{}, kt + 3, st_fill);
+                if (kt + 1 < nk) convert_item(st_next, 1);
+                if (more) dma_part(IntC<3>{}, IntC<4>{}, kt + 3, st_fill);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                seg_barrier();      // M(kt): tile kt+1 is ready
+                if (more) dma_part(IntC<4>{}, IntC<NP>{}, kt + 3, st_fill);
+                // tile kt+2 has landed: only tile kt+3 (just issued) may remain -- where it exists
+                if (kt + 3 < nk) wait_vmcnt<NP>();
+                else wait_vmcnt<0>();
+                seg_barrier();      // B(kt+1)
+                st_fill = (st_fill + 1) & 3;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumer waves
+    const int wr = wid / WN, wc = wid % WN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    uint4 ah0[TM], al0[TM], bh0[TN], bl0[TN], ah1[TM], al1[TM], bh1[TN], bl1[TN];
+    auto frag_reads = [&](int stage_idx, uint4 (&ah)[TM], uint4 (&al)[TM], uint4 (&bh)[TN], uint4 (&bl)[TN]) {
+        const unsigned char* sA = smem + stage_idx * kStage;
+        const unsigned char* sW = sA + BM * 128;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wr * (TM * 16) + i * 16 + frow;
+            ah[i] = *reinterpret_cast<const uint4*>(sA + lds_off(row, fq));
+            al[i] = *reinterpret_cast<const uint4*>(sA + lds_off(row, 4 + fq));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wc * (TN * 16) + j * 16 + frow;
+            bh[j] = *reinterpret_cast<const uint4*>(sW + lds_off(row, fq));
+            bl[j] = *reinterpret_cast<const uint4*>(sW + lds_off(row, 4 + fq));
+        }
+    };
+    // rows [I0, I1) of the wave tile: the same three products per accumulator, in the same order, as gemm_split_kernel
+    auto mfmas = [&](auto I0, auto I1, const uint4 (&ah)[TM], const uint4 (&al)[TM], const uint4 (&bh)[TN], const uint4 (&bl)[TN]) {
+#pragma unroll
+        for (int i = decltype(I0)::value; i < decltype(I1)::value; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = mfma_h(bl[j], ah[i], acc[i][j]);
+                acc[i][j] = mfma_h(bh[j], al[i], acc[i][j]);
+                acc[i][j] = mfma_h(bh[j], ah[i], acc[i][j]);
+            }
+    };
+    if (nk > 0) {
+        seg_barrier();  // P0
+        seg_barrier();  // B(0): tile 0 is ready
+        frag_reads(0, ah0, al0, bh0, bl0);
+        auto kstep = [&](int kt, uint4 (&ah)[TM], uint4 (&al)[TM], uint4 (&bh)[TN], uint4 (&bl)[TN], uint4 (&nah)[TM], uint4 (&nal)[TM],
+                         uint4 (&nbh)[TN], uint4 (&nbl)[TN]) {
+            mfmas(IntC<0>{}, IntC<TM / 2>{}, ah, al, bh, bl);
+            seg_barrier();  // M(kt): tile kt+1 is ready
+            frag_reads((kt + 1) & 3, nah, nal, nbh, nbl);  // (behind the last K step: a stale stage into registers nobody uses)
+            mfmas(IntC<TM / 2>{}, IntC<TM>{}, ah, al, bh, bl);
+            seg_barrier();  // B(kt+1)
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            kstep(kt, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1);
+            kstep(kt + 1, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0);
+        }
+        if (kt < nk) kstep(kt, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1);
+    }
+    const int mw = m0 + wr * (TM * 16), nw = n0 + wc * (TN * 16);
+    constexpr int kStrip = 32 * (TN * 16 + 4);
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0;
+    __syncthreads();  // every wave (loaders included) is done with the stages: the strips below overwrite them
+    if constexpr (TN % 2 == 0) {
+        if (p.act == GMD_ACT_GEGLU && full) {
+            epilogue_rows_geglu_f32<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, mw, nw, lane, z);
+            return;
+        }
+    }
+    if (p.ksplit > 1 && full) {
+        epilogue_rows_f32<TM, TN, true>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, mw, nw, lane, z, ks);
+        return;
+    }
+    const bool rows_ok = p.ksplit <= 1 && full && (p.ldc & 3) == 0 && (p.sC & 3) == 0 &&
+                         (p.residual == nullptr || ((p.ldr & 3) == 0 && (p.sR & 3) == 0)) &&
+                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    if (rows_ok) epilogue_rows_f32<TM, TN, false>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, mw, nw, lane, z, ks);
+    else epilogue_regs_f32<TM, TN>(p, acc, mw, nw, frow, fq, z, ks);
+}
+
 // one launch of the pre-split weight layout: out[n][kb][plane][q][j], plane 0 = hi, 1 = lo; chunk q holds
 // k = kb*32 + {4q..4q+3, 16+4q..16+4q+3}
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int64_t N, int64_t K, int64_t ldw) {
@@ -640,6 +938,36 @@ hipError_t launch_split(const GemmParams& p, int gz, hipStream_t s) {
     return hipGetLastError();
 }
 
+// 0 (default): never; -1: the loader / converter kernel where it fits (GMD_SPLIT_LC=1); 1: wherever it is instantiated
+// (gmd_gemm_plan_override(.., pf = 244, ..); pf = 9: never).  NOT the default: alone on the chip it wins 3-9 % on one-round launches,
+// but in the two-stream float32 pipeline the whole run is 2.3 % SLOWER with it (bench.py tolerance_path 1894 -> 1937 ms per batch,
+// gpurun_out/s2): like the 16-bit loader-wave kernels it owns its CU (144 KB of LDS), and a workgroup of the other stream on the same
+// CU was already hiding what the loader waves hide.  Kept for single-stream users and as the measured answer
+// to "take the operand split out of the float32 main loop".
+int g_split_lc_mode = [] { const char* e = getenv("GMD_SPLIT_LC"); return (e && e[0] == '1') ? -1 : 0; }();
+
+template <bool CONV, int TN>
+hipError_t launch_split_lc(const GemmParams& p, int gz, hipStream_t s) {
+    constexpr int BM = 128, BN = 2 * TN * 16;
+    constexpr size_t smem = (size_t)4 * (BM + BN) * 128;
+    hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_split_lc_kernel<CONV, TN>), (int)smem);
+    if (e != hipSuccess) return e;
+    dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);
+    gemm_split_lc_kernel<CONV, TN><<<grid, 512, smem, s>>>(p);
+    return hipGetLastError();
+}
+
+// the loader / converter kernel runs ONE workgroup per CU: taken when the launch's 128-row tiles come in (nearly) whole rounds of 256
+bool split_lc_fits(const SplitPlan& pl, const GemmParams& p, int batch) {
+    if (g_split_lc_mode == 0 || batch != 1 || pl.bm != 128 || p.K / BKS < 4) return false;
+    if (g_split_lc_mode == 1) return true;
+    // measured (tools/ab_split_lc.py, bit-identical results): +3...+9 % where the launch is ONE round of workgroups (conv 8x32x32
+    // 640->640 208 -> 196 us, 4x64x64 320->320 110 -> 102 us, linear M=8192 N=640 K=2560 101 -> 95 us); launches of several rounds lose
+    // 10-28 % to two co-resident workgroups of the ring kernel, which overlap one tile's epilogue with the next one's prologue
+    const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + pl.bn - 1) / pl.bn) * (pl.ksplit > 1 ? pl.ksplit : 1);
+    return tiles >= 200 && tiles <= 256;
+}
+
 template <bool CONV, bool WSPLIT>
 int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     SplitPlan pl = make_split_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0);
@@ -661,7 +989,8 @@ int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStr
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
     hipError_t e;
-    if (pl.bm == 128 && pl.bn == 160) e = launch_split<CONV, WSPLIT, 2, 2, 4, 5, 2>(p, gz, s);
+    if (WSPLIT && split_lc_fits(pl, p, batch)) e = pl.bn == 160 ? launch_split_lc<CONV, 5>(p, gz, s) : launch_split_lc<CONV, 4>(p, gz, s);
+    else if (pl.bm == 128 && pl.bn == 160) e = launch_split<CONV, WSPLIT, 2, 2, 4, 5, 2>(p, gz, s);
     else if (pl.bm == 128) e = launch_split<CONV, WSPLIT, 2, 2, 4, 4, 2>(p, gz, s);
     else e = launch_split<CONV, WSPLIT, 2, 2, 2, 2, 2>(p, gz, s);
     if (e == hipSuccess && pl.ksplit > 1 && !p.defer_reduce) {
@@ -704,6 +1033,8 @@ int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int 
 
 // split-K factor launch_split_any will choose (no GEGLU): gmd_conv3x3_groupnorm / gmd_conv3x3_gn_fusable of gemm.hip
 int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes) { return make_split_plan(M, N, K, 1, ws_bytes).ksplit; }
+
+void gmd_split_set_lc(int mode) { g_split_lc_mode = mode; }
 
 // called by gmd_gemm_nt / gmd_conv3x3 (gemm.hip) for the two split dtype codes; the parameter block is validated there
 int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {

@@ -505,3 +505,50 @@ def test_split_kernels_emit_producer_statistics_for_groupnorm(B, H, ci, co):
         assert rel_err(a, ref) < 2e-6 and rel_err(bref, ref) < 2e-6
     finally:
         o.set_f32_mode(prev)
+
+
+@pytest.mark.parametrize("case", ["conv 8x32x32 64->640", "conv 3x24x20 64->320 s2", "gemm 8192x640x640 res", "gemm 1000x328x320 ragged", "geglu 2048x2560x320",
+                                  "gemm 1024x1280x2560 k-slices"])
+def test_split_loader_converter_kernel_is_bit_identical_to_the_in_register_split(case):
+    """gemm_split_lc_kernel (round 4: the loader waves split a landed activation tile once, in place in LDS; the consumers read ready
+    f16 fragments) forms the same three products per accumulator in the same order as gemm_split_kernel (every wave splits its
+    fragments in registers): results must be equal bit for bit -- full and ragged tiles, convolution addressing, GEGLU, K slices."""
+    import os
+
+    from gm_diffusion._native import lib
+    o = ops()
+    g = torch.Generator().manual_seed(len(case))
+    prev_env = os.environ.get("GMD_TUNING")
+    os.environ["GMD_TUNING"] = "1"
+    prev = o.set_f32_mode("split")
+    try:
+        if case.startswith("conv"):
+            B, H, W, ci, co, kw = (8, 32, 32, 64, 640, {}) if "8x32" in case else (3, 24, 20, 64, 320, dict(stride=2))
+            x = torch.randn(B, H * W, ci, generator=g).to(DEV)
+            w = o.split_weights((torch.randn(co, 9 * ci, generator=g) * 0.05).to(DEV))
+            b, tb = torch.randn(co, generator=g).to(DEV), torch.randn(B, co, generator=g).to(DEV)
+            fn = lambda: o.conv3x3(x, w, B, H, W, bias=b, rowbias=tb, **kw)[0]
+        else:
+            M, N, K = {"gemm 8192x640x640 res": (8192, 640, 640), "gemm 1000x328x320 ragged": (1000, 328, 320), "geglu 2048x2560x320": (2048, 2560, 320),
+                       "gemm 1024x1280x2560 k-slices": (1024, 1280, 2560)}[case]
+            a = torch.randn(M, K, generator=g).to(DEV)
+            w = o.split_weights((torch.randn(N, K, generator=g) * 0.05).to(DEV))
+            b = torch.randn(N, generator=g).to(DEV)
+            kw = dict(bias=b)
+            if "res" in case:
+                kw["residual"] = torch.randn(M, N, generator=g).to(DEV)
+            if "geglu" in case:
+                kw["act"] = o.ACT_GEGLU
+            fn = lambda: o.gemm_nt(a, w, **kw)
+        assert lib().gmd_gemm_plan_override(0, 0, 9, 0) == 0      # in-register split (round-3 kernel)
+        y0 = fn()
+        assert lib().gmd_gemm_plan_override(0, 0, 244, 0) == 0    # loader / converter kernel wherever it is instantiated
+        y1 = fn()
+        assert torch.isfinite(y0).all() and torch.equal(y0, y1)
+    finally:
+        lib().gmd_gemm_plan_override(0, 0, 0, 0)
+        o.set_f32_mode(prev)
+        if prev_env is None:
+            os.environ.pop("GMD_TUNING", None)
+        else:
+            os.environ["GMD_TUNING"] = prev_env
