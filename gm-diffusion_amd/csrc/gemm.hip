@@ -280,46 +280,16 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (p.colstats) {  // lane -> column (and column 64 + lane): 32 conflict-free reads each, fixed order
-#pragma unroll
-            for (int k = 0; k < (NCOL + 63) / 64; ++k) {
-                const int cc = lane + 64 * k;
-                if (cc < NCOL) {
-                    float s_ = 0.f, q_ = 0.f;
-#pragma unroll 8
-                    for (int r = 0; r < 32; ++r) {
-                        const float x = strip[r * ROWF + cc];
-                        s_ += x;
-                        q_ += x * x;
-                    }
-                    cs[k] += s_;
-                    cq[k] += q_;
-                }
-            }
+        if (p.colstats) {  // lane -> column (and column 64 + lane): 32 conflict-free reads each, fixed order (gemm_shared.h)
+            colstats_pass<NCOL, ROWF>(strip, lane, cs, cq);
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (p.colstats) {  // fold cs_bucket adjacent columns; the wave tile's TM*16 rows are one row block of the statistics
-#pragma unroll
-        for (int k = 0; k < (NCOL + 63) / 64; ++k) {
-            const int cc = lane + 64 * k;
-            if (cc < NCOL) {
-                strip[cc] = cs[k];
-                strip[ROWF + cc] = cq[k];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int nb = NCOL / p.cs_bucket;
-        if (lane < nb) {
-            float s_ = 0.f, q_ = 0.f;
-            for (int e = 0; e < p.cs_bucket; ++e) {
-                s_ += strip[lane * p.cs_bucket + e];
-                q_ += strip[ROWF + lane * p.cs_bucket + e];
-            }
-            float* o = p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket + lane) * 2;
-            *reinterpret_cast<float2*>(o) = make_float2(s_, q_);
-        }
-    }
+    // producer statistics for a following GroupNorm: {sum, sum of squares} of the STORED values over this wave tile's TM*16 = 64
+    // rows (one row block of the statistics) and each bucket of cs_bucket adjacent columns
+    if (p.colstats)
+        colstats_store<NCOL, ROWF>(strip, lane, cs, cq, p.cs_bucket,
+                                   p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket) * 2);
 }
 
 // Split-K variant of epilogue_rows: the raw float32 partial sums of a full tile go to this slice's slab as whole row

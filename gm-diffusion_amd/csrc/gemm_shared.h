@@ -123,6 +123,61 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// ---- producer column statistics: the column pass of the row epilogues (gemm.hip epilogue_rows, gemm_split.hip epilogue_rows_f32) ----
+// One float32 add that the compiler can neither pack with a neighbour nor fold away.  The column pass below keeps {sum, sum of
+// squares} pairs; hipcc (ROCm 7.2) packs the pair updates into v_pk_add_f32 and, where the pair order of the two operands
+// differs, adds `op_sel:[0,1] op_sel_hi:[1,0]`.  With the float32 kernels' register allocation that swizzled form sat two
+// instructions in front of an EXEC change (the `column < NCOL` branch of the next 64 columns), and under a second stream's load
+// lanes 48..63 of its low result came out without one of the two addends on three different MI355X (tools/stress_colstats.py:
+// 1 launch in 200-1500).  Both halves of the pattern are gone: these adds are single v_add_f32, and the column
+// loops run with every lane active (clamped column), only the stores predicated.
+__device__ __forceinline__ float add_f32_single(float a, float b) {
+    float r;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// cs[k] / cq[k] += column sums of the strip's 32 rows for column lane + 64 k (lanes past NCOL re-read the last column: never stored)
+template <int NCOL, int ROWF>
+__device__ __forceinline__ void colstats_pass(const float* strip, int lane, float (&cs)[(NCOL + 63) / 64], float (&cq)[(NCOL + 63) / 64]) {
+#pragma unroll
+    for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+        const int cc = lane + 64 * k < NCOL ? lane + 64 * k : NCOL - 1;
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+            const float x = strip[r * ROWF + cc];
+            s_ += x;
+            q_ += x * x;
+        }
+        cs[k] = add_f32_single(cs[k], s_);
+        cq[k] = add_f32_single(cq[k], q_);
+    }
+}
+
+// {sum, sum of squares} of each bucket of `bucket` adjacent columns of this wave tile -> out[(row block) * (N / bucket) + ...]
+template <int NCOL, int ROWF>
+__device__ __forceinline__ void colstats_store(float* strip, int lane, const float (&cs)[(NCOL + 63) / 64], const float (&cq)[(NCOL + 63) / 64],
+                                               int bucket, float* out) {
+#pragma unroll
+    for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+        const int cc = lane + 64 * k;
+        if (cc < NCOL) {
+            strip[cc] = cs[k];
+            strip[ROWF + cc] = cq[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nb = NCOL / bucket;
+    const int b0 = (lane < nb ? lane : nb - 1) * bucket;  // every lane folds a bucket (the idle ones the last): no EXEC change around the adds
+    float s_ = 0.f, q_ = 0.f;
+    for (int e = 0; e < bucket; ++e) {
+        s_ = add_f32_single(s_, strip[b0 + e]);
+        q_ = add_f32_single(q_, strip[ROWF + b0 + e]);
+    }
+    if (lane < nb) *reinterpret_cast<float2*>(out + lane * 2) = make_float2(s_, q_);
+}
+
 constexpr int BK = 64;  // bf16 elements per K step = 128 bytes = 8 chunks of 16 bytes
 
 // byte offset of 16-byte chunk `chunk` of row `row` in a [rows][128 B] tile; the XOR makes both the

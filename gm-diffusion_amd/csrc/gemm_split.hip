@@ -219,48 +219,16 @@ __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32
                 *reinterpret_cast<float4*>(strip + r * ROWF + c * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
         __builtin_amdgcn_wave_barrier();
-        if (!SLAB && p.colstats) {  // lane -> column (and column 64 + lane): 32 conflict-free reads each, fixed order
-#pragma unroll
-            for (int k = 0; k < (NCOL + 63) / 64; ++k) {
-                const int cc = lane + 64 * k;
-                if (cc < NCOL) {
-                    float s_ = 0.f, q_ = 0.f;
-#pragma unroll 8
-                    for (int r = 0; r < 32; ++r) {
-                        const float x = strip[r * ROWF + cc];
-                        s_ += x;
-                        q_ += x * x;
-                    }
-                    cs[k] += s_;
-                    cq[k] += q_;
-                }
-            }
+        if (!SLAB && p.colstats) {  // lane -> column (and column 64 + lane): 32 conflict-free reads each, fixed order (gemm_shared.h)
+            colstats_pass<NCOL, ROWF>(strip, lane, cs, cq);
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // producer statistics for a following GroupNorm, the layout of the 16-bit kernels (gemm.hip: epilogue_rows): {sum, sum of
-    // squares} of the STORED values over this wave tile's 64 rows and each bucket of cs_bucket adjacent columns
-    if (!SLAB && p.colstats) {
-#pragma unroll
-        for (int k = 0; k < (NCOL + 63) / 64; ++k) {
-            const int cc = lane + 64 * k;
-            if (cc < NCOL) {
-                strip[cc] = cs[k];
-                strip[ROWF + cc] = cq[k];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int nb = NCOL / p.cs_bucket;
-        if (lane < nb) {
-            float s_ = 0.f, q_ = 0.f;
-            for (int e = 0; e < p.cs_bucket; ++e) {
-                s_ += strip[lane * p.cs_bucket + e];
-                q_ += strip[ROWF + lane * p.cs_bucket + e];
-            }
-            float* o = p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket + lane) * 2;
-            *reinterpret_cast<float2*>(o) = make_float2(s_, q_);
-        }
-    }
+    // producer statistics for a following GroupNorm: {sum, sum of squares} of the STORED values over this wave tile's TM*16 = 64
+    // rows (one row block of the statistics) and each bucket of cs_bucket adjacent columns
+    if (!SLAB && p.colstats)
+        colstats_store<NCOL, ROWF>(strip, lane, cs, cq, p.cs_bucket,
+                                   p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket) * 2);
 }
 
 // GEGLU (GEGLU.forward of diffusers: value * gelu_erf(gate)): the W rows are interleaved at load time in 16-row [value | gate]
