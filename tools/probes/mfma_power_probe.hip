@@ -1,7 +1,7 @@
 // Sustained matrix-core rate of register-resident MFMA streams on the whole chip, by instruction shape and operand data:
 // is the ~1.0-1.1 PFLOP/s the GEMM / conv kernels reach on random data (profiles/r04_zero_data_probe.txt) a property of the
 // kernels or of the chip's power management, and does the 32x32x16 shape sustain more than 16x16x32?   (measurement tool only)
-//   hipcc -O3 --offload-arch=gfx950 -o mfma_power_probe mfma_power_probe.hip && ./mfma_power_probe
+//   hipcc -O3 --offload-arch=gfx950 -o mfma_power_probe mfma_power_probe.hip && ./mfma_power_probe [iterations [data 0|1|2 [type 0|1]]]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -108,6 +108,7 @@ static void run(const char* name, const u32x4* d, float* out, int wgs, int iters
 
 int main(int argc, char** argv) {
     const int wgs = 256, iters = argc > 1 ? atoi(argv[1]) : 400000;
+    const int only_data = argc > 2 ? atoi(argv[2]) : -1, only_half = argc > 3 ? atoi(argv[3]) : -1;  // restrict to one data pattern / type
     const size_t n = (size_t)wgs * 512 * 8;  // u32x4 per thread: 8
     std::vector<u32x4> h(n);
     u32x4* d; float* out;
@@ -115,6 +116,7 @@ int main(int argc, char** argv) {
     hipMalloc(&out, (size_t)wgs * 512 * 4);
     for (int data = 0; data < 3; ++data) {  // 0: zeros, 1: random normal bf16 / f16, 2: all ones
         for (int half = 0; half < 2; ++half) {
+            if ((only_data >= 0 && data != only_data) || (only_half >= 0 && half != only_half)) continue;
             srand(1);
             for (size_t i = 0; i < n; ++i) {
                 unsigned short v[8];
