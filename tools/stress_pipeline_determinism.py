@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Whole-pipeline repeatability under the shipped execution mode: StableDiffusionDualUNetPipeline at SD-1.5 width (512x512, batch 4,
+STEPS PNDM steps) run once eagerly on one stream, then REPS times with captured graphs + two streams; every run's latent pair must
+equal the eager one bit for bit.  The round-4 producer-statistics fault showed as 9 mismatching runs of 10
+here; exits 1 on any mismatch.    DTYPE=f32|bf16|f16  REPS=20  STEPS=4  python tools/stress_pipeline_determinism.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gm-diffusion_amd")):
+    sys.path.insert(0, p)
+import torch
+from gm_diffusion import hip_ops as ops
+from gm_diffusion.components import PNDMScheduler, UNet2DConditionModel
+from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
+
+DEV = "cuda"
+DTYPE = os.environ.get("DTYPE", "f32")
+dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[DTYPE]
+REPS, STEPS = int(os.environ.get("REPS", "20")), int(os.environ.get("STEPS", "4"))
+ops.set_f32_mode("split")
+pipe = StableDiffusionDualUNetPipeline(
+    vae=None, text_encoder=None, tokenizer=None,
+    unet=UNet2DConditionModel(in_channels=4).init_random(7, device=DEV).to(DEV, dt),
+    gm_unet=UNet2DConditionModel(in_channels=8).init_random(8, device=DEV).to(DEV, dt),
+    scheduler=PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1,
+                            set_alpha_to_one=False), safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+pipe.set_progress_bar_config(disable=True)
+res, batch = 512, 4
+g = torch.Generator().manual_seed(res)
+pe, ne = torch.randn(batch, 77, 768, generator=g).to(DEV), torch.randn(batch, 77, 768, generator=g).to(DEV)
+lat = torch.randn(batch, 4, res // 8, res // 8, generator=g).to(DEV)
+kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=res, width=res, num_inference_steps=STEPS, guidance_scale=7.5, output_type="latent")
+pipe.use_hip_graphs, pipe.overlap_streams = False, False
+ref = pipe(**kw)
+ref = (ref[0].clone(), ref[1].clone())
+bad = 0
+for rep in range(REPS):
+    pipe.use_hip_graphs, pipe.overlap_streams = True, True
+    a = pipe(**kw)
+    torch.cuda.synchronize()
+    if not (torch.equal(a[0], ref[0]) and torch.equal(a[1], ref[1])):
+        bad += 1
+        print(f"  run {rep}: differs from the eager run (max abs {float((a[0].float() - ref[0].float()).abs().max()):.3e} / {float((a[1].float() - ref[1].float()).abs().max()):.3e})", flush=True)
+print(f"{DTYPE}: {bad} of {REPS} graphs + two-streams runs differ from the eager single-stream run ({STEPS} steps, 512x512, batch {batch})")
+sys.exit(1 if bad else 0)
