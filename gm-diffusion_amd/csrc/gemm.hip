@@ -20,10 +20,11 @@
 #include <type_traits>
 
 // gemm_split.hip: float32 on the matrix cores as three float16 products (GMD_F32S / GMD_F32SW)
-int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
-int gmd_launch_split_conv(const void* params, int w_presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
+int gmd_launch_split_gemm(const void* params, int presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
+int gmd_launch_split_conv(const void* params, int presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name);
 int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes);
 int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int bucket);
+int gmd_split_out_ok(int M, int N, int K, int geglu, int64_t ws_bytes);
 void gmd_split_set_lc(int mode);
 
 namespace {
@@ -2415,7 +2416,7 @@ int gmd_conv_patch_override(int mode) {
 }
 
 int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket) {
-    if (dtype == GMD_F32S || dtype == GMD_F32SW) return gmd_split_colstats_ok(M, N, K, batch, workspace_bytes, bucket);  // round 4
+    if (gmd_is_split(dtype)) return gmd_split_colstats_ok(M, N, K, batch, workspace_bytes, bucket);  // round 4
     if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 0;
     return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false), M, N, batch, bucket) ? 1 : 0;
 }
@@ -2427,15 +2428,24 @@ int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t worksp
     return GMD_OK;
 }
 
+// 1 when a float32-split gmd_gemm_nt launch of these dimensions can take out_dtype = GMD_F32SA (store its result pre-split)
+int gmd_gemm_out_split_ok(int M, int N, int K, int geglu, int64_t workspace_bytes) { return gmd_split_out_ok(M, N, K, geglu, workspace_bytes); }
+
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype, int M, int N, int K, int64_t lda,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,
                 const float* rowbias, int rows_per_group, int64_t ldrb, const void* residual, int64_t ldr, int64_t strideR, float alpha,
                 int act, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
-    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;  // float32 tensors, three float16 MFMA passes
+    const bool split = gmd_is_split(dtype);  // float32 tensors, three float16 MFMA passes
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32 || split, "gmd_gemm_nt: bad dtype %d", dtype);
     const bool is16 = gmd_is_half(dtype);
-    GMD_REQUIRE(out_dtype == GMD_F32 || (!split && out_dtype == dtype), "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
+    const bool c_split = split && out_dtype == GMD_F32SA;  // float32 result stored pre-split for the next contraction
+    GMD_REQUIRE(out_dtype == GMD_F32 || (!split && out_dtype == dtype) || c_split, "gmd_gemm_nt: out_dtype must be F32 or the input dtype");
     GMD_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gmd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    if (c_split) {  // full 128-row tiles through the row epilogues only: the caller asks gmd_gemm_out_split_ok first
+        const int nout = act == GMD_ACT_GEGLU ? N / 2 : N;
+        GMD_REQUIRE(batch == 1 && nout % 32 == 0 && ldc == nout && !colstats && gmd_split_out_ok(M, N, K, act == GMD_ACT_GEGLU, workspace ? workspace_bytes : 0),
+                    "gmd_gemm_nt: this launch cannot store its output pre-split (ask gmd_gemm_out_split_ok; ldc must equal the row length)");
+    }
     if (M == 0 || N == 0 || batch == 0) return GMD_OK;
     const int kmul = is16 ? 64 : split ? 32 : 4, vec = is16 ? 8 : 4;
     GMD_REQUIRE(K % kmul == 0, "gmd_gemm_nt: K=%d must be a multiple of %d", K, kmul);
@@ -2465,11 +2475,13 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     }
     p.bias = bias; p.rowbias = rowbias; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.ldrb = ldrb > 0 ? ldrb : N;
     p.residual = residual; p.ldr = ldr; p.sR = strideR; p.alpha = alpha; p.act = act;
-    p.out_f32 = out_dtype == GMD_F32;
+    p.out_f32 = out_dtype == GMD_F32 || c_split;
+    p.c_split = c_split ? 1 : 0;
     p.cblk = K;
     p.colstats = colstats; p.cs_bucket = colstats_bucket;
     if (split) {
-        return gmd_launch_split_gemm(&p, dtype == GMD_F32SW, batch, batch == 1 ? workspace : nullptr, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
+        return gmd_launch_split_gemm(&p, dtype == GMD_F32SA ? 2 : dtype == GMD_F32SW ? 1 : 0, batch, batch == 1 ? workspace : nullptr, workspace_bytes,
+                                     (hipStream_t)stream, "gmd_gemm_nt");
     }
     return launch<false>(p, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_nt");
 }
@@ -2496,7 +2508,7 @@ void conv_out_shape(int Hin, int Win, int stride, int upsample, int pad_mode, in
 
 // split-K factor the conv launch will use (1 = unsplit); the same planners the launch itself calls
 int conv_plan_ksplit(int dtype, int64_t M, int Cin, int Cout, int64_t ws_bytes) {
-    if (dtype == GMD_F32S || dtype == GMD_F32SW) return gmd_split_plan_ksplit((int)M, Cout, 9 * Cin, ws_bytes);
+    if (gmd_is_split(dtype)) return gmd_split_plan_ksplit((int)M, Cout, 9 * Cin, ws_bytes);
     if (gmd_is_half(dtype)) return make_plan((int)M, Cout, 9 * Cin, 1, ws_bytes, false).ksplit;
     return 1;
 }
@@ -2505,7 +2517,7 @@ int conv3x3_impl(const void* X, const void* Wt, void* Y, int dtype, int out_dtyp
                  int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
                  float alpha, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream,
                  const GnTail* gn) {
-    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;
+    const bool split = gmd_is_split(dtype);
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32 || split, "gmd_conv3x3: bad dtype %d", dtype);
     const bool is16 = gmd_is_half(dtype);
     GMD_REQUIRE(out_dtype == GMD_F32 || (!split && out_dtype == dtype), "gmd_conv3x3: out_dtype must be F32 or the input dtype");
@@ -2549,7 +2561,7 @@ int conv3x3_impl(const void* X, const void* Wt, void* Y, int dtype, int out_dtyp
         }
         p.defer_reduce = 1;
     }
-    const int rc = split ? gmd_launch_split_conv(&p, dtype == GMD_F32SW, B, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3")
+    const int rc = split ? gmd_launch_split_conv(&p, dtype == GMD_F32SA ? 2 : dtype == GMD_F32SW ? 1 : 0, B, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3")
                          : launch<true>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_conv3x3");
     if (rc != GMD_OK || !gn) return rc;
     return gmd_launch_gn_from_slabs((const float*)workspace, ks, alpha, bias, rowbias, p.ldrb, residual, Y, gn->Ynorm, split ? GMD_F32 : dtype, B,
@@ -2569,7 +2581,7 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
 
 int gmd_conv3x3_gn_fusable(int dtype, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode, int groups,
                            int64_t workspace_bytes) {
-    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;
+    const bool split = gmd_is_split(dtype);
     if (!(gmd_is_half(dtype) || split) || B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0) return 0;
     if (!(stride == 1 || stride == 2) || (upsample && stride != 1) || !(pad_mode == 0 || (pad_mode == 1 && stride == 2 && !upsample))) return 0;
     int Hout, Wout, pad_lo;
@@ -2588,7 +2600,7 @@ int gmd_conv3x3_groupnorm(const void* X, const void* Wt, void* Yraw, void* Ynorm
                           const void* residual, float alpha, int groups, float eps, const float* gamma, const float* beta, int silu,
                           void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     GMD_REQUIRE(Ynorm && gamma && beta && groups > 0 && gmd_aligned16(Ynorm), "gmd_conv3x3_groupnorm: null or unaligned GroupNorm argument");
-    const bool split = dtype == GMD_F32S || dtype == GMD_F32SW;
+    const bool split = gmd_is_split(dtype);
     const GnTail gn{Ynorm, groups, eps, gamma, beta, silu};
     return conv3x3_impl(X, Wt, Yraw, dtype, split ? GMD_F32 : dtype, B, Hin, Win, Cin, Cout, stride, upsample, pad_mode, bias, rowbias, ldrb,
                         residual, alpha, nullptr, 0, workspace, workspace_bytes, stream, &gn);

@@ -21,6 +21,7 @@ struct GemmParams {
     float alpha;
     int act;
     int out_f32;
+    int c_split;       // float32 split path: store the output pre-split ([hi | lo] per 32 elements, GMD_F32SA as out_dtype; full-tile row epilogues)
     unsigned a_bytes, w_bytes;  // extents of the A / W operands (one batch slab) for the buffer descriptors
     int ksplit;          // > 1: grid z splits K; raw fp32 partial sums go to `ws` [ksplit][M][N], epilogue in splitk_reduce
     float* ws;

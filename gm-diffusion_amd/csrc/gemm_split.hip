@@ -27,19 +27,7 @@ namespace {
 
 constexpr int BKS = 32;  // float32 elements per K step = 128 bytes
 
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-
-// (a, b) -> packed f16 pair hi and packed f16 pair lo = f16(x - hi)
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    const f16x2_t h = {(_Float16)a, (_Float16)b};  // v_cvt_pk_f16_f32, round to nearest even
-    const unsigned hw = __builtin_bit_cast(unsigned, h);
-    float ra, rb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hw), "v"(a));                  // a - f32(h.lo)
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hw), "v"(b));  // b - f32(h.hi)
-    const f16x2_t l = {(_Float16)ra, (_Float16)rb};
-    hi = hw;
-    lo = __builtin_bit_cast(unsigned, l);
-}
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) { gmd_split2(a, b, hi, lo); }  // gmd_common.h
 __device__ __forceinline__ void split8(const float4& x0, const float4& x1, uint4& hi, uint4& lo) {
     split2(x0.x, x0.y, hi.x, lo.x);
     split2(x0.z, x0.w, hi.y, lo.y);
@@ -214,7 +202,8 @@ __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs_f32
-            *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.c_split) gmd_store_split4((float*)p.C, (int64_t)m * p.ldc + n, v[0], v[1], v[2], v[3]);  // (batch 1, ldc = row length: host-checked)
+            else *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             if (p.colstats)  // the stored values go back to the strip for the column pass below
                 *reinterpret_cast<float4*>(strip + r * ROWF + c * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -269,8 +258,9 @@ __device__ __forceinline__ void epilogue_rows_geglu_f32(const GemmParams& p, con
             const int idx = lane + 64 * t;
             const int r = idx / CH, c = idx - r * CH;
             if (32 * CH % 64 != 0 && r >= 32) continue;
-            *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)(mw + h * 32 + r) * p.ldc + nw / 2 + c * 4) =
-                *reinterpret_cast<const float4*>(strip + r * ROWF + c * 4);
+            const float4 o4 = *reinterpret_cast<const float4*>(strip + r * ROWF + c * 4);
+            if (p.c_split) gmd_store_split4((float*)p.C, (int64_t)(mw + h * 32 + r) * p.ldc + nw / 2 + c * 4, o4.x, o4.y, o4.z, o4.w);
+            else *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)(mw + h * 32 + r) * p.ldc + nw / 2 + c * 4) = o4;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -316,7 +306,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const GemmParams
 // ------------------------------------------------------------------------------------------------
 // ring kernel: WM x WN waves, wave tile (TM*16) x (TN*16), NST-stage LDS ring filled by LDS-DMA with counted waits
 // ------------------------------------------------------------------------------------------------
-template <bool CONV, bool WSPLIT, int WM, int WN, int TM, int TN, int NST>
+// ASPLIT (round 4, GMD_F32SA): the A operand arrives pre-split like a weight -- its producer (GroupNorm / LayerNorm apply, the GEGLU
+// epilogue: gmd_store_split4) wrote [hi | lo] per 32 elements -- and the fragment is two 16-byte reads instead of two reads + 16
+// conversion instructions.  Same values, same products, same order: bit-identical to the in-kernel split.
+template <bool CONV, bool WSPLIT, int WM, int WN, int TM, int TN, int NST, bool ASPLIT = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void gemm_split_kernel(const GemmParams p) {
     constexpr int NWAVES = WM * WN;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -477,6 +470,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wr * (TM * 16) + i * 16 + frow;
+            if (ASPLIT) {
+                ah[i] = *reinterpret_cast<const uint4*>(sA + lds_off(row, fq));
+                al[i] = *reinterpret_cast<const uint4*>(sA + lds_off(row, 4 + fq));
+                continue;
+            }
             const float4 x0 = *reinterpret_cast<const float4*>(sA + lds_off(row, fq));
             const float4 x1 = *reinterpret_cast<const float4*>(sA + lds_off(row, 4 + fq));
             split8(x0, x1, ah[i], al[i]);
@@ -893,16 +891,16 @@ SplitPlan make_split_plan(int M, int N, int K, int batch, int64_t ws_bytes) {
     return pl;
 }
 
-template <bool CONV, bool WSPLIT, int WM, int WN, int TM, int TN, int NST>
+template <bool CONV, bool WSPLIT, int WM, int WN, int TM, int TN, int NST, bool ASPLIT = false>
 hipError_t launch_split(const GemmParams& p, int gz, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
     if (smem > 64 * 1024) {
-        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<CONV, WSPLIT, WM, WN, TM, TN, NST>), (int)smem);
+        hipError_t e = opt_in_lds(reinterpret_cast<const void*>(&gemm_split_kernel<CONV, WSPLIT, WM, WN, TM, TN, NST, ASPLIT>), (int)smem);
         if (e != hipSuccess) return e;
     }
     dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, gz);
-    gemm_split_kernel<CONV, WSPLIT, WM, WN, TM, TN, NST><<<grid, WM * WN * 64, smem, s>>>(p);
+    gemm_split_kernel<CONV, WSPLIT, WM, WN, TM, TN, NST, ASPLIT><<<grid, WM * WN * 64, smem, s>>>(p);
     return hipGetLastError();
 }
 
@@ -936,8 +934,9 @@ bool split_lc_fits(const SplitPlan& pl, const GemmParams& p, int batch) {
     return tiles >= 200 && tiles <= 256;
 }
 
-template <bool CONV, bool WSPLIT>
+template <bool CONV, bool WSPLIT, bool ASPLIT = false>
 int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+    static_assert(!ASPLIT || WSPLIT, "a pre-split activation meets pre-split weights only (GMD_F32SA)");
     SplitPlan pl = make_split_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0);
     if (p.act == GMD_ACT_GEGLU) {
         // value / gate tile pairs inside a wave: even TN (128x128 or 64x64 tiles), unsplit K, every tile full, row epilogue
@@ -953,14 +952,23 @@ int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStr
             return GMD_ERR_UNSUPPORTED;
         }
     }
+    if (p.c_split) {  // pre-split output: only the full-tile row epilogues write it (gmd_split_out_ok + their alignment conditions)
+        const bool rows_ok = pl.bm == 128 && pl.ksplit == 1 && batch == 1 && p.M % 128 == 0 && p.N % pl.bn == 0 && (p.ldc & 3) == 0 &&
+                             (p.residual == nullptr || (p.ldr & 3) == 0) &&
+                             (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0));
+        if (!rows_ok) {
+            gmd_set_error("%s: this float32 launch cannot store its output pre-split (ask gmd_gemm_out_split_ok first)", name);
+            return GMD_ERR_UNSUPPORTED;
+        }
+    }
     p.ksplit = pl.ksplit;
     p.ws = (float*)ws;
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
     hipError_t e;
-    if (WSPLIT && split_lc_fits(pl, p, batch)) e = pl.bn == 160 ? launch_split_lc<CONV, 5>(p, gz, s) : launch_split_lc<CONV, 4>(p, gz, s);
-    else if (pl.bm == 128 && pl.bn == 160) e = launch_split<CONV, WSPLIT, 2, 2, 4, 5, 2>(p, gz, s);
-    else if (pl.bm == 128) e = launch_split<CONV, WSPLIT, 2, 2, 4, 4, 2>(p, gz, s);
-    else e = launch_split<CONV, WSPLIT, 2, 2, 2, 2, 2>(p, gz, s);
+    if (WSPLIT && !ASPLIT && split_lc_fits(pl, p, batch)) e = pl.bn == 160 ? launch_split_lc<CONV, 5>(p, gz, s) : launch_split_lc<CONV, 4>(p, gz, s);
+    else if (pl.bm == 128 && pl.bn == 160) e = launch_split<CONV, WSPLIT, 2, 2, 4, 5, 2, ASPLIT>(p, gz, s);
+    else if (pl.bm == 128) e = launch_split<CONV, WSPLIT, 2, 2, 4, 4, 2, ASPLIT>(p, gz, s);
+    else e = launch_split<CONV, WSPLIT, 2, 2, 2, 2, 2, ASPLIT>(p, gz, s);
     if (e == hipSuccess && pl.ksplit > 1 && !p.defer_reduce) {
         const int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
         int64_t g = (total + 255) / 256;
@@ -999,20 +1007,32 @@ int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int 
     return (pl.bm == 128 && pl.ksplit == 1 && M % 128 == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0) ? 1 : 0;
 }
 
+// the launch can store its result pre-split (GemmParams::c_split): an unsplit launch of full 128-row tiles, whose row epilogues write
+// whole 4-element pieces of 32-element chunks (wave tiles start at multiples of 16 columns; GEGLU: of 8 output columns -- 64 / 80 wide)
+int gmd_split_out_ok(int M, int N, int K, int geglu, int64_t ws_bytes) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32) return 0;
+    SplitPlan pl = make_split_plan(M, N, K, 1, ws_bytes);
+    if (geglu) { if (pl.bn == 160) pl.bn = 128; pl.ksplit = 1; }
+    return (pl.bm == 128 && pl.ksplit == 1 && M % 128 == 0 && N % pl.bn == 0) ? 1 : 0;
+}
+
 // split-K factor launch_split_any will choose (no GEGLU): gmd_conv3x3_groupnorm / gmd_conv3x3_gn_fusable of gemm.hip
 int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes) { return make_split_plan(M, N, K, 1, ws_bytes).ksplit; }
 
 void gmd_split_set_lc(int mode) { g_split_lc_mode = mode; }
 
 // called by gmd_gemm_nt / gmd_conv3x3 (gemm.hip) for the two split dtype codes; the parameter block is validated there
-int gmd_launch_split_gemm(const void* params, int w_presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+// presplit: 0 = both operands plain float32 (GMD_F32S), 1 = W pre-split (GMD_F32SW), 2 = A and W pre-split (GMD_F32SA)
+int gmd_launch_split_gemm(const void* params, int presplit, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     const GemmParams& p = *reinterpret_cast<const GemmParams*>(params);
-    return w_presplit ? launch_split_any<false, true>(p, batch, ws, ws_bytes, s, name) : launch_split_any<false, false>(p, batch, ws, ws_bytes, s, name);
+    if (presplit == 2) return launch_split_any<false, true, true>(p, batch, ws, ws_bytes, s, name);
+    return presplit ? launch_split_any<false, true>(p, batch, ws, ws_bytes, s, name) : launch_split_any<false, false>(p, batch, ws, ws_bytes, s, name);
 }
-int gmd_launch_split_conv(const void* params, int w_presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
+int gmd_launch_split_conv(const void* params, int presplit, int B, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     GemmParams p = *reinterpret_cast<const GemmParams*>(params);
     p.cblk = split_channel_block(B, p.Hin, p.Win, p.Cin, p.N);
-    return w_presplit ? launch_split_any<true, true>(p, 1, ws, ws_bytes, s, name) : launch_split_any<true, false>(p, 1, ws, ws_bytes, s, name);
+    if (presplit == 2) return launch_split_any<true, true, true>(p, 1, ws, ws_bytes, s, name);
+    return presplit ? launch_split_any<true, true>(p, 1, ws, ws_bytes, s, name) : launch_split_any<true, false>(p, 1, ws, ws_bytes, s, name);
 }
 
 extern "C" int gmd_split_weights(const float* W, void* out, int64_t N, int64_t K, int64_t ldw, gmd_stream_t stream) {

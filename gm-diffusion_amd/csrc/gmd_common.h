@@ -155,6 +155,9 @@ int gmd_launch_gn_from_slabs(const float* ws, int ksplit, float alpha, const flo
 
 static inline bool gmd_is_half(int dtype) { return dtype == GMD_BF16 || dtype == GMD_F16; }
 static inline bool gmd_known_dtype(int dtype) { return dtype == GMD_F32 || gmd_is_half(dtype); }
+// float32 tensors contracted on the matrix cores as three float16 passes (gemm_split.hip): both operands plain / W pre-split /
+// both pre-split (GMD_F32SA, round 4: producers store activations as [hi 64 B | lo 64 B] per 32 elements)
+static inline bool gmd_is_split(int dtype) { return dtype == GMD_F32S || dtype == GMD_F32SW || dtype == GMD_F32SA; }
 // run f(T{}) with T = float / bf16_t / f16_t (the caller has validated the code)
 template <typename F>
 static inline void gmd_for_dtype(int dtype, F&& f) {
@@ -164,6 +167,33 @@ static inline void gmd_for_dtype(int dtype, F&& f) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- float32 -> (hi, lo) float16 pairs: x = hi + lo, hi = f16(x), lo = f16(x - hi) (gemm_split.hip) ----
+typedef __attribute__((ext_vector_type(2))) _Float16 gmd_f16x2_t;
+// (a, b) -> packed f16 pair hi and packed f16 pair lo
+__device__ __forceinline__ void gmd_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const gmd_f16x2_t h = {(_Float16)a, (_Float16)b};  // v_cvt_pk_f16_f32, round to nearest even
+    const unsigned hw = __builtin_bit_cast(unsigned, h);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hw), "v"(a));                  // a - f32(h.lo)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hw), "v"(b));  // b - f32(h.hi)
+    const gmd_f16x2_t l = {(_Float16)ra, (_Float16)rb};
+    hi = hw;
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// Pre-split storage of a float32 tensor whose rows are multiples of 32 elements (GMD_F32SA activations, the layout of
+// gmd_split_weights): every 32-element chunk (128 bytes, the same bytes as the float32 values) holds [hi 64 B | lo 64 B]; inside each
+// half, 16-byte piece q (0..3) holds elements {4q .. 4q+3, 16+4q .. 16+4q+3} -- the k's lane group q of a 16x16x32 MFMA consumes.
+// Stores elements e .. e+3 (e % 4 == 0; element index over the whole tensor) of the tensor at Y.
+__device__ __forceinline__ void gmd_store_split4(float* Y, int64_t e, float v0, float v1, float v2, float v3) {
+    unsigned char* cb = reinterpret_cast<unsigned char*>(Y + (e & ~(int64_t)31));
+    const int ci = (int)(e & 31), off = ((ci & 15) >> 2) * 16 + (ci >> 4) * 8;
+    unsigned h0, l0, h1, l1;
+    gmd_split2(v0, v1, h0, l0);
+    gmd_split2(v2, v3, h1, l1);
+    *reinterpret_cast<uint2*>(cb + off) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(cb + 64 + off) = make_uint2(l0, l1);
+}
 
 // Wave-wide reductions on the data-parallel-primitive (DPP) path: quad permutes, then the two row mirrors, then the four
 // 16-lane rows are met through v_readlane -- ~11 short VALU / SALU instructions instead of six ds_bpermute round trips

@@ -138,7 +138,19 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict_
 // partial sums of ITS sample (8 lanes per group over a fixed strided subset, then a fixed-order shuffle tree -- the same
 // deterministic order as gn_finalize_kernel), builds the per-channel scale / shift in LDS, then normalises its slice of the
 // sample's rows.  The redundant fold costs ~1 us per workgroup and saves the finalize launch (6.5 us of pure latency).
-template <typename T>
+// GMD_F32SA as the dtype of an apply kernel: float32 in, the OUTPUT stored pre-split for the next contraction (gmd_common.h:
+// gmd_store_split4; `e` = element index of v[0] over the whole tensor, rows are multiples of 32 elements)
+template <bool SPLIT_OUT, typename T, int V>
+__device__ __forceinline__ void store_vec_maybe_split(T* Y, int64_t e, const float (&v)[V]) {
+    if constexpr (SPLIT_OUT) {
+        static_assert(sizeof(T) == 4 && V == 4, "pre-split output is a float32 format");
+        gmd_store_split4(reinterpret_cast<float*>(Y), e, v[0], v[1], v[2], v[3]);
+    } else {
+        store_vec(Y + e, v);
+    }
+}
+
+template <typename T, bool SPLIT_OUT = false>
 __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t HW, int C, int G,
                                                                int nsplit, float eps, const float* __restrict__ ws,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
 #pragma unroll
             for (int j = 0; j < V; ++j) v[j] = silu_f(v[j]);
         }
-        store_vec(Yb + i * V, v);
+        store_vec_maybe_split<SPLIT_OUT>(Yb, i * V, v);
     }
 }
 
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
 // of two producers' outputs (the up blocks' skip connections): channels < Ca take their sums from sa [rows/64][Ca/bucket][2],
 // the others from sb [rows/64][(C-Ca)/bucket][2].  Same fold as gn_apply_ws_kernel (8 lanes per group over a fixed strided
 // subset of its (row block, bucket) items, double accumulation, fixed-order shuffle tree): deterministic.
-template <typename T>
+template <typename T, bool SPLIT_OUT = false>
 __global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t HW, int C, int G,
                                                                float eps, const float* __restrict__ sa, int Ca,
                                                                const float* __restrict__ sb, int bucket,
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restri
 #pragma unroll
             for (int j = 0; j < V; ++j) v[j] = silu_f(v[j]);
         }
-        store_vec(Yb + i * V, v);
+        store_vec_maybe_split<SPLIT_OUT>(Yb, i * V, v);
     }
 }
 
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void gn_slab_kernel(const SlabSource sp, 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers, exact two-pass variance.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MAXCH, int ROWS>
+template <typename T, int MAXCH, int ROWS, bool SPLIT_OUT = false>
 __global__ __launch_bounds__(kThreads) void layernorm_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps) {
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const T* __restrict
                     const int c = chunk * V + j;
                     o[j] = (v[rr][k][j] - mean) * rstd * gamma[c] + beta[c];
                 }
-                store_vec(Y + (row0 + rr) * C + (int64_t)chunk * V, o);
+                store_vec_maybe_split<SPLIT_OUT>(Y, (row0 + rr) * C + (int64_t)chunk * V, o);
             }
         }
     }
@@ -818,10 +830,11 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
     GMD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0, "gmd_groupnorm_split: bad shape B=%d HW=%lld C=%d G=%d", B, (long long)HW, C, G);
     GMD_REQUIRE(X && Y && gamma && beta && workspace, "gmd_groupnorm_split: null pointer");
     GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y), "gmd_groupnorm_split: pointers must be 16-byte aligned");
-    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_groupnorm_split: bad dtype %d", dtype);
+    const bool split_out = dtype == GMD_F32SA;  // float32 in, output stored pre-split
+    GMD_REQUIRE(gmd_known_dtype(dtype) || split_out, "gmd_groupnorm_split: bad dtype %d", dtype);
     GMD_REQUIRE(B <= 65535, "gmd_groupnorm_split: batch too large");
     const int V = gmd_is_half(dtype) ? 8 : 4;
-    GMD_REQUIRE(C % V == 0, "gmd_groupnorm_split: C=%d must be a multiple of %d", C, V);
+    GMD_REQUIRE(C % V == 0 && (!split_out || C % 32 == 0), "gmd_groupnorm_split: C=%d must be a multiple of %d", C, split_out ? 32 : V);
     const int nsplit = gmd_groupnorm_nsplit(HW);
     const int CV = C / V, CVB = CV < kThreads ? CV : kThreads, PY = kThreads / CVB;
     const size_t smem = (size_t)PY * C * 2 * sizeof(float);
@@ -836,6 +849,12 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
         using T = decltype(tag);
         gn_partial_kernel<T><<<dim3(nsplit, B), kThreads, smem, s>>>((const T*)X, HW, C, G, nsplit, workspace);
         if (hipGetLastError() != hipSuccess) { partial_ok = false; return; }
+        if constexpr (sizeof(T) == 4) {
+            if (split_out) {
+                gn_apply_ws_kernel<T, true><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, nsplit, eps, workspace, gamma, beta, silu);
+                return;
+            }
+        }
         gn_apply_ws_kernel<T><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, nsplit, eps, workspace, gamma, beta, silu);
     });
     if (!partial_ok) {
@@ -852,10 +871,11 @@ int gmd_groupnorm_colstats(const void* X, void* Y, int dtype, int B, int64_t HW,
     GMD_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0, "gmd_groupnorm_colstats: bad shape B=%d HW=%lld C=%d G=%d", B, (long long)HW, C, G);
     GMD_REQUIRE(X && Y && gamma && beta && stats_a, "gmd_groupnorm_colstats: null pointer");
     GMD_REQUIRE(gmd_aligned16(X) && gmd_aligned16(Y), "gmd_groupnorm_colstats: pointers must be 16-byte aligned");
-    GMD_REQUIRE(gmd_known_dtype(dtype), "gmd_groupnorm_colstats: bad dtype %d", dtype);
+    const bool split_out = dtype == GMD_F32SA;  // float32 in, output stored pre-split
+    GMD_REQUIRE(gmd_known_dtype(dtype) || split_out, "gmd_groupnorm_colstats: bad dtype %d", dtype);
     GMD_REQUIRE(B <= 65535, "gmd_groupnorm_colstats: batch too large");
     const int V = gmd_is_half(dtype) ? 8 : 4;
-    GMD_REQUIRE(C % V == 0 && (size_t)C * 8 <= 64 * 1024, "gmd_groupnorm_colstats: C=%d must be a multiple of %d and at most 8192", C, V);
+    GMD_REQUIRE(C % V == 0 && (!split_out || C % 32 == 0) && (size_t)C * 8 <= 64 * 1024, "gmd_groupnorm_colstats: C=%d must be a multiple of %d and at most 8192", C, split_out ? 32 : V);
     GMD_REQUIRE(HW % 64 == 0, "gmd_groupnorm_colstats: the statistics are per 64-row block, HW=%lld is not a multiple of 64", (long long)HW);
     GMD_REQUIRE(bucket > 0 && (C / G) % bucket == 0 && Ca > 0 && Ca <= C && Ca % bucket == 0 && (C - Ca) % bucket == 0,
                 "gmd_groupnorm_colstats: bucket=%d must divide the group size %d and both channel ranges (%d, %d)", bucket, C / G, Ca, C - Ca);
@@ -867,6 +887,13 @@ int gmd_groupnorm_colstats(const void* X, void* Y, int dtype, int B, int64_t HW,
     if (nb > HW) nb = HW;
     gmd_for_dtype(dtype, [&](auto tag) {
         using T = decltype(tag);
+        if constexpr (sizeof(T) == 4) {
+            if (split_out) {
+                gn_apply_cs_kernel<T, true><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, eps, stats_a, Ca,
+                                                                                                  stats_b, bucket, gamma, beta, silu);
+                return;
+            }
+        }
         gn_apply_cs_kernel<T><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, eps, stats_a, Ca,
                                                                                     stats_b, bucket, gamma, beta, silu);
     });
@@ -967,6 +994,9 @@ int gmd_layernorm(const void* X, void* Y, int dtype, int64_t rows, int C, const 
     } else if (dtype == GMD_F32) {
         GMD_REQUIRE(C % 4 == 0, "gmd_layernorm: C=%d must be a multiple of 4", C);
         layernorm_kernel<float, 8, 1><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, rows, C, gamma, beta, eps);
+    } else if (dtype == GMD_F32SA) {  // float32 in, output stored pre-split (the A operand of the projections that follow)
+        GMD_REQUIRE(C % 32 == 0, "gmd_layernorm: a pre-split output needs C=%d to be a multiple of 32", C);
+        layernorm_kernel<float, 8, 1, true><<<grid, kThreads, 0, s>>>((const float*)X, (float*)Y, rows, C, gamma, beta, eps);
     } else {
         GMD_REQUIRE(false, "gmd_layernorm: bad dtype %d", dtype);
     }

@@ -14,9 +14,9 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
-GMD_F32, GMD_BF16, GMD_F16, GMD_F32S, GMD_F32SW = 0, 1, 2, 3, 4
+GMD_F32, GMD_BF16, GMD_F16, GMD_F32S, GMD_F32SW, GMD_F32SA = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
@@ -45,6 +45,7 @@ SIGNATURES = {
     "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, I, P, L, P],
     "gmd_gemm_colstats_plan": [I, I, I, I, I, L, I],
     "gmd_gemm_plan_info": [I, I, I, I, I, L, I, P],
+    "gmd_gemm_out_split_ok": [I, I, I, I, L],
     "gmd_conv_patch_override": [I],
     "gmd_stamp": [P, P, I, I, P],
     "gmd_split_weights": [P, P, L, L, L, P],

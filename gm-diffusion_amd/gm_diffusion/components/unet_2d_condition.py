@@ -515,13 +515,19 @@ class UNet2DConditionModel(_HipModule):
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _sa(*ws):
+        """Store the activation that feeds these weights PRE-SPLIT (hip_ops: GMD_F32SA)?  Only when every consumer weight is itself
+        pre-split, i.e. the float32 matrix-core mode; the producers then write [hi | lo] and the contractions skip their conversions."""
+        return ops.USE_F32SA and all(getattr(w, "_split", False) for w in ws)
+
     def _resnet(self, r, x, B, H, W, temb, eps):
         G = self.config.norm_num_groups
         cs = self._wants_colstats(H, W)  # the GroupNorm that reads a conv output takes its statistics from the conv epilogue
-        h = ops.groupnorm(x, B, G, r["n1"][0], r["n1"][1], eps, silu=True)
+        h = ops.groupnorm(x, B, G, r["n1"][0], r["n1"][1], eps, silu=True, split_out=self._sa(r["c1"][0]))
         # conv1 -> + time embedding -> norm2 -> SiLU: one GroupNorm launch over the split-K slabs on the 16x16 / 8x8 levels
         _, h = ops.conv3x3_groupnorm(h, r["c1"][0], B, H, W, G, r["n2"][0], r["n2"][1], eps, silu=True, bias=r["c1"][1],
-                                     rowbias=(temb, r["te_off"]), colstats=cs)
+                                     rowbias=(temb, r["te_off"]), colstats=cs, split_out=self._sa(r["c2"][0]))
         if "sc" in r:
             cin = x.shape[-1]
             x = ops.gemm_nt(x.view(-1, cin), r["sc"][0], bias=r["sc"][1]).view(B, H * W, -1)
@@ -540,7 +546,10 @@ class UNet2DConditionModel(_HipModule):
         scale = d ** -0.5
         qk = ops.gemm_nt(n1, t["qk1"]).view(B, N, 2 * C)
         if ops.is_half(self._dtype) or ops.split_attention_ok(self._dtype, d):
-            vt = ops.gemm_nt(t["v1"], n1.view(B, N, C), ldc=_pad_to(N, 8 if ops.is_half(self._dtype) else 4))  # V^T [B, C, N]
+            nv = n1.view(B, N, C)
+            if ops.is_asplit(n1):  # a pre-split activation as the W operand of V^T = Wv n1^T: exactly the pre-split weight layout
+                nv._split, nv._alpha = True, 1.0
+            vt = ops.gemm_nt(t["v1"], nv, ldc=_pad_to(N, 8 if ops.is_half(self._dtype) else 4))  # V^T [B, C, N]
             return ops.attention(qk, qk, vt, heads, N, scale, k_col=C)
         npad = _pad_to(N, 4)
         if npad != N:
@@ -598,8 +607,8 @@ class UNet2DConditionModel(_HipModule):
         text conditioning; everything up to the first cross-attention query is computed once, then duplicated (returns 2B rows)."""
         C = x.shape[-1]
         N = H * W
-        h = ops.groupnorm(x, B, self.config.norm_num_groups, t["norm"][0], t["norm"][1], 1e-6, silu=False)
-        h = ops.gemm_nt(h.view(B * N, C), t["pin"][0], bias=t["pin"][1])  # conv1x1 and nn.Linear proj_in are the same GEMM on tokens
+        h = ops.groupnorm(x, B, self.config.norm_num_groups, t["norm"][0], t["norm"][1], 1e-6, silu=False, split_out=self._sa(t["pin"][0]))
+        h = ops.gemm_nt(h.view(B * N, C), t["pin"][0], bias=t["pin"][1], a_split=ops.is_asplit(h))  # conv1x1 and nn.Linear proj_in are the same GEMM on tokens
         for blk in t["blocks"]:
             h, x, B = self._transformer_block(blk, h, x, B, N, C, ehs, cfg_dup)
             cfg_dup = False  # the first cross-attention has duplicated the batch
@@ -611,11 +620,12 @@ class UNet2DConditionModel(_HipModule):
         heads = t["heads"]
         d = C // heads
         # self-attention
-        n1 = ops.layernorm(h, *t["norm1"])
+        # (the V^T product takes n1 as its W operand: pre-split only where the matrix-core attention path is taken)
+        n1 = ops.layernorm(h, *t["norm1"], split_out=self._sa(t["qk1"]) and ops.split_attention_ok(self._dtype, d))
         o = self._self_attention(t, n1, B, N, C)
         h = ops.gemm_nt(o.view(B * N, C), t["o1"][0], bias=t["o1"][1], residual=h)
         # cross-attention over the text tokens
-        n2 = ops.layernorm(h, *t["norm2"])
+        n2 = ops.layernorm(h, *t["norm2"], split_out=self._sa(t["q2"]))
         q = ops.gemm_nt(n2, t["q2"]).view(B, N, C)
         if cfg_dup:  # first use of the text conditioning: from here on the two halves differ
             q, h, x = self._dup_batch(q), self._dup_batch(h.view(B, N, C)).view(2 * B * N, C), self._dup_batch(x)
@@ -628,12 +638,12 @@ class UNet2DConditionModel(_HipModule):
             o = composed_attention(q, 0, C, kc, 0, C, vtc, B, heads, d, N, L, d ** -0.5, self._dtype)
         h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h)
         # GEGLU feed-forward
-        n3 = ops.layernorm(h, *t["norm3"])
+        n3 = ops.layernorm(h, *t["norm3"], split_out=self._sa(t["ff1"][0]))
         if t["ff1_fused"] and ops.ff_fused_ok(n3, C):  # the whole feed-forward in one launch: [tokens, 4C] never reaches HBM
             h = ops.ff_geglu_fused(n3, t["ff1"][0], t["ff1"][1], t["ff2"][0], t["ff2"][1], h)
         else:
-            if t["ff1_fused"]:
-                f = ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1], act=ops.ACT_GEGLU)  # h * gelu(g) formed in the GEMM epilogue
+            if t["ff1_fused"]:  # h * gelu(g) formed in the GEMM epilogue (float32 matrix-core mode: stored pre-split for ff2)
+                f = ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1], act=ops.ACT_GEGLU, split_out=self._sa(t["ff2"][0]))
             else:
                 f = ops.geglu(ops.gemm_nt(n3, t["ff1"][0], bias=t["ff1"][1]))
             h = ops.gemm_nt(f, t["ff2"][0], bias=t["ff2"][1], residual=h)
@@ -778,7 +788,7 @@ class UNet2DConditionModel(_HipModule):
                 x, H, W = ops.conv3x3(x, blk["us"][0], B, H, W, bias=blk["us"][1], upsample=True,
                                       colstats=self._wants_colstats(2 * H, 2 * W))
             mark()  # end of an up block
-        x = ops.groupnorm(x, B, c.norm_num_groups, w["norm_out"][0], w["norm_out"][1], eps, silu=True)
+        x = ops.groupnorm(x, B, c.norm_num_groups, w["norm_out"][0], w["norm_out"][1], eps, silu=True, split_out=self._sa(w["conv_out"][0]))
         y, _, _ = ops.conv3x3(x, w["conv_out"][0], B, H, W, bias=w["conv_out"][1], out_dtype=torch.float32)
         out = ops.unpack_nchw(y, B, c.out_channels, H, W)
         mark()  # end of the forward

@@ -19,7 +19,7 @@ import time
 import torch
 
 from . import profiling
-from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F16, GMD_F32, GMD_F32S, GMD_F32SW, HipExtensionError, check, lib
+from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F16, GMD_F32, GMD_F32S, GMD_F32SA, GMD_F32SW, HipExtensionError, check, lib
 
 __all__ = [
     "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows", "set_f32_mode", "f32_split", "split_weights", "scale_weight", "split_attention_ok", "ff_fused_ok", "ff_geglu_fused", "dup_batch",
@@ -117,12 +117,51 @@ def scale_weight(w):
     return out
 
 
-def _contract_code(a, w, K):
+# Round 4: float32 activations stored PRE-SPLIT between a producer and the contraction that reads them (GMD_F32SA, gmd_hip.h): the
+# GroupNorm / LayerNorm apply kernels and the GEGLU epilogue write [hi 64 B | lo 64 B] per 32 elements, the split kernels then read both
+# operands as ready float16 fragments.  Results are bit-identical to the in-kernel split.  GMD_F32SA=0 switches the format off (A/B).
+USE_F32SA = os.environ.get("GMD_F32SA", "1") != "0"
+
+
+def is_asplit(t):
+    """The tensor holds float32 values in the pre-split activation layout (only ever the A / W operand of a contraction)."""
+    return bool(getattr(t, "_asplit", False))
+
+
+def _mark_asplit(t):
+    t._asplit = True
+    return t
+
+
+def want_split_out(dtype, row_len):
+    """A producer may store its float32 output pre-split: split mode on the matrix cores, rows of whole 32-element chunks."""
+    return USE_F32SA and dtype == torch.float32 and F32_MODE == "split" and row_len % 32 == 0
+
+
+def split_activation(x):
+    """float32 [..., C] (C % 32 == 0) -> the same values in the pre-split activation layout (tests / tools; the product's producers
+    write the layout themselves)."""
+    _dev(x)
+    _f32(x, "split_activation input")
+    C = x.shape[-1]
+    if C % 32:
+        raise HipExtensionError("split_activation: rows must be multiples of 32 elements")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib().gmd_split_weights(_ptr(x), _ptr(out), x.numel() // C, C, C, _stream()), "gmd_split_weights")
+    return _mark_asplit(out)
+
+
+def _contract_code(a, w, K, a_split=False):
     """dtype code of a contraction of ``a`` with the W operand ``w`` over K."""
     if a.dtype != torch.float32:
         if getattr(w, "_split", False):
             raise HipExtensionError("a pre-split float32 weight met a 16-bit activation")
         return dtype_code(a.dtype)
+    if a_split:
+        if not getattr(w, "_split", False):
+            raise HipExtensionError("a pre-split activation needs a pre-split weight operand (GMD_F32SA)")
+        return GMD_F32SA
     if getattr(w, "_split", False):
         return GMD_F32SW
     return GMD_F32S if (F32_MODE == "split" and K % 32 == 0) else GMD_F32
@@ -242,7 +281,7 @@ def _colstats_buffer(want, dtype, M, N, K, batch, out_dtype, device, code=None):
         return None
     if is_half(dtype):
         code = dtype_code(dtype)
-    elif code not in (GMD_F32S, GMD_F32SW):
+    elif code not in (GMD_F32S, GMD_F32SW, GMD_F32SA):
         return None
     if not lib().gmd_gemm_colstats_plan(code, M, N, K, batch, WORKSPACE_BYTES, COLSTATS_BUCKET):
         return None
@@ -275,7 +314,7 @@ def carry_colstats(dst, src):
 
 
 def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=1.0, act=ACT_NONE,
-            out_dtype=None, out=None, ldc=None, colstats=False):
+            out_dtype=None, out=None, ldc=None, colstats=False, a_split=False, split_out=False):
     """``act(alpha * a @ w.T + bias + rowbias[m // rows_per_group] + residual)``.
 
     a: [M, K] or [batch, M, K]; w: [N, K] or [batch, N, K] (a 2-D operand is shared by the batch)."""
@@ -290,7 +329,8 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     N = w.shape[-2]
     if w.shape[-1] != K:
         raise HipExtensionError(f"gemm_nt: K mismatch {a.shape} vs {w.shape}")
-    dt = _contract_code(a, w, K)
+    a_split = bool(a_split) or is_asplit(a)   # ``a_split``: a VIEW of a pre-split activation (views do not carry the mark)
+    dt = _contract_code(a, w, K, a_split)
     if getattr(a, "_split", False):
         raise HipExtensionError("gemm_nt: a pre-split weight can only be the W operand")
     alpha = float(alpha) * getattr(a, "_alpha", 1.0) * getattr(w, "_alpha", 1.0)  # weights stored scaled by a power of two
@@ -310,13 +350,20 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     if bias is not None and bias.numel() != N:
         raise HipExtensionError("gemm_nt: bias must have N elements")
     ws = _workspace(a.device) if batch == 1 else None
+    # pre-split OUTPUT (the A operand of the next contraction): where the launch's plan can write it, else the plain tensor
+    oc = dtype_code(out_dtype)
+    c_split = False
+    if (split_out and dt in (GMD_F32S, GMD_F32SW, GMD_F32SA) and batch == 1 and a.dim() == 2 and w.dim() == 2 and residual is None and not colstats
+            and want_split_out(out_dtype, ldc) and ldc == (N // 2 if act == ACT_GEGLU else N)
+            and lib().gmd_gemm_out_split_ok(M, N, K, int(act == ACT_GEGLU), WORKSPACE_BYTES)):
+        oc, c_split = GMD_F32SA, True
     st = None
     if colstats and batch == 1 and a.dim() == 2 and w.dim() == 2 and act != ACT_GEGLU and ldc == N:
         st = _colstats_buffer(True, a.dtype, M, N, K, 1, out_dtype, a.device, code=dt)
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("gemm_nt") else None
     t0 = tm.begin() if tm else None
-    check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, dtype_code(out_dtype), M, N, K, K, K, ldc, batch, sA, sW, sC,
+    check(lib().gmd_gemm_nt(_ptr(a), _ptr(w), _ptr(out), dt, oc, M, N, K, K, K, ldc, batch, sA, sW, sC,
                             _ptr(_f32(bias, "bias")), rb_ptr, rows_per_group, rb_ld,
                             _ptr(residual), N, sR, float(alpha), act, _ptr(st), COLSTATS_BUCKET if st is not None else 0,
                             _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_gemm_nt")
@@ -327,6 +374,8 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
         out._colstats = (st, N)
     elif getattr(out, "_colstats", None) is not None:  # a reused `out=` buffer must not keep an earlier producer's statistics
         del out._colstats
+    if c_split:
+        _mark_asplit(out)
     return out
 
 
@@ -362,7 +411,7 @@ def ff_geglu_fused(x, w1i, b1i, w2, b2, residual):
 
 
 def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, upsample=False, pad_mode=0, out_dtype=None,
-            colstats=False):
+            colstats=False, x_split=False):
     """x: [B, H*W, Cin]; w: [Cout, 9*Cin] (tap-major); returns ([B, Hout*Wout, Cout], Hout, Wout)."""
     _dev(x, w, bias, residual)
     rb_ptr, rb_ld = _rowbias(rowbias)
@@ -382,11 +431,13 @@ def conv3x3(x, w, B, H, W, bias=None, rowbias=None, residual=None, stride=1, ups
     if rowbias is not None and (rowbias[0] if isinstance(rowbias, tuple) else rowbias).shape[0] != B:
         raise HipExtensionError("conv3x3: rowbias must have one row per sample")
     ws = _workspace(x.device)
-    st = _colstats_buffer(colstats, x.dtype, B * ho * wo, cout, 9 * cin, 1, out_dtype, x.device, code=_contract_code(x, w, cin))
+    x_split = bool(x_split) or is_asplit(x)
+    code = _contract_code(x, w, cin, x_split)
+    st = _colstats_buffer(colstats, x.dtype, B * ho * wo, cout, 9 * cin, 1, out_dtype, x.device, code=code)
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("conv3x3") else None
     t0 = tm.begin() if tm else None
-    check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), _contract_code(x, w, cin), dtype_code(out_dtype), B, H, W, cin, cout,
+    check(lib().gmd_conv3x3(_ptr(x), _ptr(w), _ptr(y), code, dtype_code(out_dtype), B, H, W, cin, cout,
                             stride, int(upsample), pad_mode, _ptr(_f32(bias, "bias")), rb_ptr, rb_ld,
                             _ptr(residual), float(getattr(w, "_alpha", 1.0)), _ptr(st), COLSTATS_BUCKET if st is not None else 0,
                             _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_conv3x3")
@@ -402,18 +453,18 @@ USE_CONV_GN_FUSION = os.environ.get("GMD_CONV_GN", "1") != "0"  # (the switch: A
 
 
 def conv3x3_groupnorm(x, w, B, H, W, groups, gamma, beta, eps, silu=True, bias=None, rowbias=None, residual=None, want_raw=False,
-                      colstats=False):
+                      colstats=False, split_out=False):
     """GroupNorm(+SiLU) of conv3x3(x): returns (raw or None, normalised).  Where the convolution runs split-K and the group slices
     are small (the 16x16 / 8x8 UNet levels) ONE GroupNorm launch sums the partial slabs, applies the convolution's epilogue and
     normalises (gmd_conv3x3_groupnorm: no reduce launch, the raw tensor is written only if ``want_raw``); everywhere else this
     is conv3x3 (+ producer statistics if ``colstats``) followed by groupnorm -- bit-identical either way."""
     _dev(x, w, bias, residual, gamma, beta)
     cin, cout = x.shape[-1], w.shape[0]
-    code = _contract_code(x, w, cin) if x.dtype == w.dtype and w.shape[1] == 9 * cin else -1
+    code = _contract_code(x, w, cin, is_asplit(x)) if x.dtype == w.dtype and w.shape[1] == 9 * cin else -1
     if not (USE_CONV_GN_FUSION and code >= 0 and
             lib().gmd_conv3x3_gn_fusable(code, B, H, W, cin, cout, 1, 0, 0, groups, WORKSPACE_BYTES)):
         y, _, _ = conv3x3(x, w, B, H, W, bias=bias, rowbias=rowbias, residual=residual, colstats=colstats)
-        return (y if want_raw else None), groupnorm(y, B, groups, gamma, beta, eps, silu=silu)
+        return (y if want_raw else None), groupnorm(y, B, groups, gamma, beta, eps, silu=silu, split_out=split_out)
     if x.numel() != B * H * W * cin:
         raise HipExtensionError(f"conv3x3_groupnorm: shape mismatch x={tuple(x.shape)} B,H,W={B},{H},{W}")
     if residual is not None and (residual.numel() != B * H * W * cout or residual.dtype != x.dtype):
@@ -533,7 +584,7 @@ def _usable_colstats(x, B, HW, C, cpg):
     return (parts[0], parts[1] if len(parts) == 2 else None) if len(parts) <= 2 else None
 
 
-def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
+def groupnorm(x, B, groups, gamma, beta, eps, silu=False, split_out=False):
     """GroupNorm(+SiLU).  A tensor that still carries its producer's column statistics (``colstats=True`` of gemm_nt /
     conv3x3, possibly through concat_channels) is normalised in one pass over it; otherwise small group slabs (16x16 / 8x8
     UNet levels) take the single-launch fused kernel and larger ones the split-statistics path (partial + apply)."""
@@ -546,6 +597,11 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
     # algorithmic HBM bytes of a GroupNorm: the activation is read once and written once (the statistics pass of the split
     # path re-reads it: that second read is what the roofline fraction of this kind exposes)
     nbytes = 2 * x.numel() * x.element_size()
+    if is_asplit(x):
+        raise HipExtensionError("groupnorm: the input is a pre-split activation (only contractions read that layout)")
+    # ``split_out``: store the float32 result pre-split for the contraction that reads it (the two large-slab paths; the single-launch
+    # kernel of the small levels keeps the plain layout) -- the result then carries the mark (is_asplit)
+    so = bool(split_out) and want_split_out(x.dtype, C)
     st = _usable_colstats(x, B, HW, C, cpg)
     if st is not None:
         global colstats_uses
@@ -553,13 +609,13 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
         (sa, ca), sb = st
         y = torch.empty_like(x)
         tm, t0 = _timed("groupnorm")
-        check(lib().gmd_groupnorm_colstats(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps),
+        check(lib().gmd_groupnorm_colstats(_ptr(x), _ptr(y), GMD_F32SA if so else dtype_code(x.dtype), B, HW, C, groups, float(eps),
                                            _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(sa), ca,
                                            _ptr(sb[0]) if sb is not None else None, COLSTATS_BUCKET, int(silu), _stream()),
               "gmd_groupnorm_colstats")
         if tm:
             tm.end("groupnorm", 0.0, nbytes, t0)
-        return y
+        return _mark_asplit(y) if so else y
     if cpg % epw == 0 and HW * cpg * x.element_size() <= (GN_FUSED_MAX_SLAB_VEC16 if vec16 else GN_FUSED_MAX_SLAB):
         y = torch.empty_like(x)
         tm, t0 = _timed("groupnorm")
@@ -572,27 +628,31 @@ def groupnorm(x, B, groups, gamma, beta, eps, silu=False):
     ws = torch.empty(B * nsplit * groups * 2, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     tm, t0 = _timed("groupnorm")
-    check(lib().gmd_groupnorm_split(_ptr(x), _ptr(y), dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
+    check(lib().gmd_groupnorm_split(_ptr(x), _ptr(y), GMD_F32SA if so else dtype_code(x.dtype), B, HW, C, groups, float(eps), _ptr(_f32(gamma, "gamma")),
                                     _ptr(_f32(beta, "beta")), _ptr(ws), int(silu), _stream()), "gmd_groupnorm_split")
     if tm:
         tm.end("groupnorm", 0.0, nbytes, t0)
-    return y
+    return _mark_asplit(y) if so else y
 
 
 def groupnorm_split(x, B, groups, gamma, beta, eps, silu=False):
     return groupnorm_apply(x, B, groupnorm_scale_shift(x, B, groups, gamma, beta, eps), silu)
 
 
-def layernorm(x, gamma, beta, eps=1e-5):
+def layernorm(x, gamma, beta, eps=1e-5, split_out=False):
+    """``split_out``: store the float32 result pre-split for the projections that read it (the result carries the mark, is_asplit)."""
     _dev(x, gamma, beta)
+    if is_asplit(x):
+        raise HipExtensionError("layernorm: the input is a pre-split activation (only contractions read that layout)")
     C = x.shape[-1]
+    so = bool(split_out) and want_split_out(x.dtype, C)
     y = torch.empty_like(x)
     tm, t0 = _timed("layernorm")
-    check(lib().gmd_layernorm(_ptr(x), _ptr(y), dtype_code(x.dtype), x.numel() // C, C, _ptr(_f32(gamma, "gamma")),
+    check(lib().gmd_layernorm(_ptr(x), _ptr(y), GMD_F32SA if so else dtype_code(x.dtype), x.numel() // C, C, _ptr(_f32(gamma, "gamma")),
                               _ptr(_f32(beta, "beta")), float(eps), _stream()), "gmd_layernorm")
     if tm:
         tm.end("layernorm", 0.0, 2 * x.numel() * x.element_size(), t0)
-    return y
+    return _mark_asplit(y) if so else y
 
 
 def geglu(x):

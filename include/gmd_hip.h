@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 9
+#define GMD_ABI_VERSION 10
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -47,6 +47,13 @@ extern "C" {
  * pipeline in float32 (scripts/inference/experiments/formal_improved.py:199): this is that precision at matrix-core speed. */
 #define GMD_F32S 3  /* both operands plain float32, split in the kernel */
 #define GMD_F32SW 4 /* W operand pre-split by gmd_split_weights (weights: split once when a model is placed on the device) */
+/* Round 4: float32 ACTIVATIONS stored pre-split -- every 32-element chunk of a row (128 bytes, the bytes of the 32 float32 values) holds
+ * [hi 64 B | lo 64 B] in the order of gmd_split_weights.  As `dtype` of gmd_gemm_nt / gmd_conv3x3(_groupnorm): the A operand AND W are
+ * pre-split (no conversion instruction in the main loop; results bit-identical to GMD_F32SW on the plain tensor).  As `out_dtype` of
+ * gmd_gemm_nt (GEGLU and plain row epilogues of the split types) and as `dtype` of gmd_layernorm / gmd_groupnorm_colstats /
+ * gmd_groupnorm_split: float32 tensors in, the OUTPUT stored pre-split (rows must be multiples of 32 elements).  Such a tensor is
+ * only ever an A (or W) operand of a contraction: nothing else reads it. */
+#define GMD_F32SA 5
 
 /* epilogue activation for gmd_gemm_nt */
 #define GMD_ACT_NONE 0
@@ -227,6 +234,10 @@ int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t wo
  * loader waves on a 128- or 64-row tile, for launches with about one tile per CU, round 4).  Pure host function: tests and measurement tools use
  * it to know what they exercise; nothing in the product path calls it.  Returns GMD_ERR_INVALID for other element types. */
 int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4);
+
+/* 1 when a float32-split gmd_gemm_nt launch of these dimensions (batch 1) can take out_dtype = GMD_F32SA, i.e. store its [M, N] (GEGLU:
+ * [M, N/2]) result pre-split for the contraction that follows: an unsplit launch of full 128-row tiles through the row epilogues. */
+int gmd_gemm_out_split_ok(int M, int N, int K, int geglu, int64_t workspace_bytes);
 
 /* Debug facility like gmd_gemm_plan_override (refused unless the process has GMD_TUNING=1): how stride-1 gmd_conv3x3 launches on
  * 256-row ping-pong tiles fetch their activations -- 2 (the default) = the tile's input patch resident in LDS, continuous consumers;

@@ -570,3 +570,111 @@ def test_producer_statistics_are_exact_under_a_second_streams_load(dtype):
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_colstats.py")], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert "launches with differing statistics" in p.stdout
+
+
+# ---- round 4: float32 activations stored pre-split between a producer and the contraction that reads them (GMD_F32SA) ----
+@pytest.mark.parametrize("case", ["gemm 8192x640x640 res", "gemm 32768x320x1280", "gemm 1000x328x320 ragged", "gemm 2048x1280x1280 (64x64 tiles)",
+                                  "gemm 1024x1280x2560 k-slices", "geglu 8192x5120x640", "conv 8x32x32 64->640 rowbias", "conv 3x24x20 64->320 s2",
+                                  "conv 4x16x16 640->1280 k-slices", "batched W operand"])
+def test_presplit_activation_operand_is_bit_identical_to_the_in_kernel_split(case):
+    """GMD_F32SA: the A operand arrives as [hi 64 B | lo 64 B] per 32 elements (what the GroupNorm / LayerNorm / GEGLU producers store);
+    the kernel reads ready float16 fragments.  Same split values, same products, same order -> the same bits as the plain operand."""
+    o = ops()
+    g = torch.Generator().manual_seed(len(case))
+    if case.startswith("conv"):
+        B, H, W_, ci, co, kw = {"conv 8x32x32 64->640 rowbias": (8, 32, 32, 64, 640, {}), "conv 3x24x20 64->320 s2": (3, 24, 20, 64, 320, dict(stride=2)),
+                                "conv 4x16x16 640->1280 k-slices": (4, 16, 16, 640, 1280, {})}[case]
+        x = torch.randn(B, H * W_, ci, generator=g).to(DEV)
+        w = o.split_weights((torch.randn(co, 9 * ci, generator=g) * 0.03).to(DEV))
+        b = torch.randn(co, generator=g).to(DEV)
+        if "rowbias" in case:
+            kw = dict(kw, rowbias=torch.randn(B, co, generator=g).to(DEV))
+        ref = o.conv3x3(x, w, B, H, W_, bias=b, **kw)[0]
+        got = o.conv3x3(o.split_activation(x), w, B, H, W_, bias=b, **kw)[0]
+        got2 = o.conv3x3(o.split_activation(x).view(B, H * W_, ci), w, B, H, W_, bias=b, x_split=True, **kw)[0]  # a view: explicit flag
+        assert torch.equal(ref, got) and torch.equal(ref, got2)
+        return
+    if case == "batched W operand":  # V^T = Wv n^T with the activation as the (batched) W operand: it takes the pre-split WEIGHT path
+        a = (torch.randn(320, 320, generator=g) * 0.05).to(DEV)
+        n = torch.randn(4, 1024, 320, generator=g).to(DEV)
+        ref = o.gemm_nt(a, n)
+        ns = o.split_activation(n.view(-1, 320)).view(4, 1024, 320)
+        ns._split, ns._alpha = True, 1.0
+        assert torch.equal(ref, o.gemm_nt(a, ns))
+        return
+    M, N, K = {"gemm 8192x640x640 res": (8192, 640, 640), "gemm 32768x320x1280": (32768, 320, 1280), "gemm 1000x328x320 ragged": (1000, 328, 320),
+               "gemm 2048x1280x1280 (64x64 tiles)": (2048, 1280, 1280), "gemm 1024x1280x2560 k-slices": (1024, 1280, 2560), "geglu 8192x5120x640": (8192, 5120, 640)}[case]
+    a = torch.randn(M, K, generator=g).to(DEV)
+    w = o.split_weights((torch.randn(N, K, generator=g) * 0.03).to(DEV))
+    kw = dict(bias=torch.randn(N, generator=g).to(DEV))
+    if "res" in case:
+        kw["residual"] = torch.randn(M, N, generator=g).to(DEV)
+    if case.startswith("geglu"):
+        kw["act"] = o.ACT_GEGLU
+    ref = o.gemm_nt(a, w, **kw)
+    assert torch.equal(ref, o.gemm_nt(o.split_activation(a), w, **kw))
+    with pytest.raises(o.HipExtensionError):  # the format exists for pre-split weights only
+        o.gemm_nt(o.split_activation(a), torch.randn(N, K, generator=g).to(DEV))
+
+
+def test_producers_store_the_presplit_activation_layout():
+    """LayerNorm, both large-slab GroupNorm paths and the GEGLU epilogue with ``split_out``: the bytes they store are
+    gmd_split_weights of the plain result (so the contraction that follows reads exactly the values the plain path would split)."""
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    as_bytes = lambda t: t.contiguous().view(torch.uint8)
+    # LayerNorm
+    x = torch.randn(4096, 640, generator=g).to(DEV)
+    ga, be = torch.randn(640, generator=g).to(DEV), torch.randn(640, generator=g).to(DEV)
+    y, ys = o.layernorm(x, ga, be), o.layernorm(x, ga, be, split_out=True)
+    assert o.is_asplit(ys) and not o.is_asplit(y) and torch.equal(as_bytes(ys), as_bytes(o.split_activation(y)))
+    # GroupNorm: statistics-launch path (no producer statistics attached) and producer-statistics path
+    B, H, C = 4, 32, 320
+    xg = torch.randn(B, H * H, C, generator=g).to(DEV)
+    ga, be = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    y, ys = o.groupnorm(xg, B, 32, ga, be, 1e-5, silu=True), o.groupnorm(xg, B, 32, ga, be, 1e-5, silu=True, split_out=True)
+    assert o.is_asplit(ys) and torch.equal(as_bytes(ys), as_bytes(o.split_activation(y)))
+    w = o.split_weights((torch.randn(C, 9 * 32, generator=g) * 0.05).to(DEV))
+    B, H = 4, 64  # 512 tiles of 128 x 160: the statistics-emitting plan
+    xc = torch.randn(B, H * H, 32, generator=g).to(DEV)
+    yc, _, _ = o.conv3x3(xc, w, B, H, H, colstats=True)
+    assert getattr(yc, "_colstats", None) is not None
+    before = o.colstats_uses
+    y, ys = o.groupnorm(yc, B, 32, ga, be, 1e-5, silu=True), o.groupnorm(yc, B, 32, ga, be, 1e-5, silu=True, split_out=True)
+    assert o.colstats_uses == before + 2 and o.is_asplit(ys) and torch.equal(as_bytes(ys), as_bytes(o.split_activation(y)))
+    # small slabs take the single-launch kernel: plain layout, no mark (the caller's contraction then splits in the kernel)
+    xs = torch.randn(2, 64, 1280, generator=g).to(DEV)
+    gs, bs = torch.randn(1280, generator=g).to(DEV), torch.randn(1280, generator=g).to(DEV)
+    assert not o.is_asplit(o.groupnorm(xs, 2, 32, gs, bs, 1e-5, silu=True, split_out=True))
+    # GEGLU epilogue
+    a = torch.randn(8192, 640, generator=g).to(DEV)
+    wf = o.split_weights((torch.randn(5120, 640, generator=g) * 0.03).to(DEV))
+    bf = torch.randn(5120, generator=g).to(DEV)
+    f, fs = o.gemm_nt(a, wf, bias=bf, act=o.ACT_GEGLU), o.gemm_nt(a, wf, bias=bf, act=o.ACT_GEGLU, split_out=True)
+    assert o.is_asplit(fs) and torch.equal(as_bytes(fs), as_bytes(o.split_activation(f)))
+    # a launch whose plan cannot write the layout returns the plain tensor, unmarked
+    small = o.gemm_nt(a[:96], wf, bias=bf, act=o.ACT_GEGLU, split_out=True)
+    assert not o.is_asplit(small) and torch.equal(small, f[:96])
+    # only contractions read the layout
+    with pytest.raises(o.HipExtensionError):
+        o.layernorm(ys, ga, be)  # (the mark lives on the tensor object: views are flagged by the caller, a_split= / x_split=)
+
+
+def test_unet_forward_is_bit_identical_with_and_without_presplit_activations():
+    """The whole SD-1.5-width float32 UNet forward (matrix-core mode) with the pre-split activation format on and off: same bits."""
+    from gm_diffusion.components import UNet2DConditionModel
+
+    o = ops()
+    u = UNet2DConditionModel(in_channels=8).init_random(3, device=DEV).to(DEV, torch.float32)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 32, 32, generator=g).to(DEV)
+    ehs = torch.randn(2, 77, 768, generator=g).to(DEV)
+    prev = o.USE_F32SA
+    try:
+        o.USE_F32SA = True
+        a = u(x, 500, encoder_hidden_states=ehs, return_dict=False)[0].clone()
+        o.USE_F32SA = False
+        b = u(x, 500, encoder_hidden_states=ehs, return_dict=False)[0].clone()
+    finally:
+        o.USE_F32SA = prev
+    assert torch.isfinite(a).all() and torch.equal(a, b)
