@@ -20,7 +20,7 @@
 
 // attention_split.hip: float32 tensors, three float16 MFMA passes per contraction (GMD_F32S)
 int gmd_launch_attention_split(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int D, int Nq, int Nk, int64_t ldq,
-                               int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQ, int64_t sK, int64_t sVt, int64_t sO, float scale,
+                               int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQ, int64_t sK, int64_t sVt, int64_t sO, float scale, int o_split,
                                hipStream_t stream);
 
 namespace {
@@ -827,7 +827,8 @@ int dispatch_attn(const AttnParams& p, int B, int H, int D, int Nq, int Nk, int 
 extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void* O, int dtype, int B, int H, int D, int Nq,
                              int Nk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t strideQ, int64_t strideK,
                              int64_t strideVt, int64_t strideO, float scale, int causal, gmd_stream_t stream) {
-    if (dtype == GMD_F32S) {  // float32 tensors, both contractions as three float16 products (attention_split.hip)
+    if (dtype == GMD_F32S || dtype == GMD_F32SA) {  // float32 tensors, both contractions as three float16 products (attention_split.hip);
+                                                     // GMD_F32SA: O stored pre-split for the out-projection that reads it
         GMD_REQUIRE(!causal, "gmd_attention: the float32 (split) kernel has no causal mask");
         GMD_REQUIRE(B >= 0 && H > 0 && Nq >= 0 && Nk > 0, "gmd_attention: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
         if (B == 0 || Nq == 0) return GMD_OK;
@@ -839,8 +840,10 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
         GMD_REQUIRE((int64_t)Nk * ldk < (1ll << 29) && (int64_t)D * ldvt < (1ll << 29), "gmd_attention: K / V^T slab of one head exceeds 2 GiB");
         GMD_REQUIRE(ldvt >= ((Nk + 3) / 4) * 4, "gmd_attention: ldvt=%lld must cover Nk=%d rounded up to 4", (long long)ldvt, Nk);
         GMD_REQUIRE(ldq >= (int64_t)H * D && ldk >= (int64_t)H * D && ldo >= (int64_t)H * D, "gmd_attention: row stride smaller than H*D");
+        GMD_REQUIRE(dtype != GMD_F32SA || (ldo % 32 == 0 && strideO == (int64_t)Nq * ldo && (H * D) % 4 == 0),
+                    "gmd_attention: a pre-split output needs contiguous rows of whole 32-element chunks (ldo=%lld)", (long long)ldo);
         return gmd_launch_attention_split(Q, K, Vt, O, B, H, D, Nq, Nk, ldq, ldk, ldvt, ldo, strideQ, strideK, strideVt, strideO, scale,
-                                          (hipStream_t)stream);
+                                          dtype == GMD_F32SA ? 1 : 0, (hipStream_t)stream);
     }
     if (dtype != GMD_BF16 && dtype != GMD_F16) {
         gmd_set_error("gmd_attention: GMD_BF16 / GMD_F16 / GMD_F32S are implemented (the exact F32 path composes gmd_gemm_nt + gmd_softmax_rows)");

@@ -25,6 +25,7 @@ struct AttnSplitParams {
     int Nq, Nk, H;
     int64_t ldq, ldk, ldvt, ldo, sQ, sK, sVt, sO;
     float scale_log2;  // softmax scale * log2(e)
+    int o_split;       // store O pre-split for the out-projection (GMD_F32SA: O contiguous [B][Nq][ldo], ldo % 32 == 0)
 };
 
 constexpr int KV = 64;      // keys per tile
@@ -324,8 +325,11 @@ __global__ __launch_bounds__(256, D <= 64 ? 2 : 1) void attn_split_kernel(const 
     for (int t = 0; t < (32 * CH + 63) / 64; ++t) {
         const int idx = lane + 64 * t;
         const int rr = idx / CH, cc = idx - rr * CH;
-        if (rr < 32 && q0w + rr < p.Nq)
-            *reinterpret_cast<float4*>(Ow + (int64_t)rr * p.ldo + cc * 4) = *reinterpret_cast<const float4*>(strip + rr * SROW + cc * 16);
+        if (rr < 32 && q0w + rr < p.Nq) {
+            const float4 o4 = *reinterpret_cast<const float4*>(strip + rr * SROW + cc * 16);
+            if (p.o_split) gmd_store_split4(p.O, (int64_t)(Ow - p.O) + (int64_t)rr * p.ldo + cc * 4, o4.x, o4.y, o4.z, o4.w);
+            else *reinterpret_cast<float4*>(Ow + (int64_t)rr * p.ldo + cc * 4) = o4;
+        }
     }
 }
 
@@ -348,8 +352,9 @@ hipError_t launch_attn_split(const AttnSplitParams& p, int B, hipStream_t s) {
 // called by gmd_attention (attention.hip) for dtype GMD_F32S; arguments validated there
 int gmd_launch_attention_split(const void* Q, const void* K, const void* Vt, void* O, int B, int H, int D, int Nq, int Nk, int64_t ldq,
                                int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQ, int64_t sK, int64_t sVt, int64_t sO, float scale,
-                               hipStream_t stream) {
+                               int o_split, hipStream_t stream) {
     AttnSplitParams p;
+    p.o_split = o_split;
     p.Q = (const float*)Q; p.K = (const float*)K; p.Vt = (const float*)Vt; p.O = (float*)O;
     p.Nq = Nq; p.Nk = Nk; p.H = H;
     p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.sQ = sQ; p.sK = sK; p.sVt = sVt; p.sO = sO;

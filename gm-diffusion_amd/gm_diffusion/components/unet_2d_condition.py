@@ -550,7 +550,7 @@ class UNet2DConditionModel(_HipModule):
             if ops.is_asplit(n1):  # a pre-split activation as the W operand of V^T = Wv n1^T: exactly the pre-split weight layout
                 nv._split, nv._alpha = True, 1.0
             vt = ops.gemm_nt(t["v1"], nv, ldc=_pad_to(N, 8 if ops.is_half(self._dtype) else 4))  # V^T [B, C, N]
-            return ops.attention(qk, qk, vt, heads, N, scale, k_col=C)
+            return ops.attention(qk, qk, vt, heads, N, scale, k_col=C, split_out=self._sa(t["o1"][0]))
         npad = _pad_to(N, 4)
         if npad != N:
             vt = torch.zeros((B, C, npad), dtype=self._dtype, device=n1.device)
@@ -623,7 +623,7 @@ class UNet2DConditionModel(_HipModule):
         # (the V^T product takes n1 as its W operand: pre-split only where the matrix-core attention path is taken)
         n1 = ops.layernorm(h, *t["norm1"], split_out=self._sa(t["qk1"]) and ops.split_attention_ok(self._dtype, d))
         o = self._self_attention(t, n1, B, N, C)
-        h = ops.gemm_nt(o.view(B * N, C), t["o1"][0], bias=t["o1"][1], residual=h)
+        h = ops.gemm_nt(o.view(B * N, C), t["o1"][0], bias=t["o1"][1], residual=h, a_split=ops.is_asplit(o))
         # cross-attention over the text tokens
         n2 = ops.layernorm(h, *t["norm2"], split_out=self._sa(t["q2"]))
         q = ops.gemm_nt(n2, t["q2"]).view(B, N, C)
@@ -633,10 +633,10 @@ class UNet2DConditionModel(_HipModule):
         kc, vtc = self._cross_kv(t, ehs)
         L = ehs.shape[1]
         if ops.is_half(self._dtype) or ops.split_attention_ok(self._dtype, d):
-            o = ops.attention(q, kc, vtc, heads, L, d ** -0.5)
+            o = ops.attention(q, kc, vtc, heads, L, d ** -0.5, split_out=self._sa(t["o2"][0]))
         else:
             o = composed_attention(q, 0, C, kc, 0, C, vtc, B, heads, d, N, L, d ** -0.5, self._dtype)
-        h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h)
+        h = ops.gemm_nt(o.view(B * N, C), t["o2"][0], bias=t["o2"][1], residual=h, a_split=ops.is_asplit(o))
         # GEGLU feed-forward
         n3 = ops.layernorm(h, *t["norm3"], split_out=self._sa(t["ff1"][0]))
         if t["ff1_fused"] and ops.ff_fused_ok(n3, C):  # the whole feed-forward in one launch: [tokens, 4C] never reaches HBM

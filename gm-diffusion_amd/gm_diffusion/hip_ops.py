@@ -496,9 +496,10 @@ def split_attention_ok(dtype, d):
     return dtype == torch.float32 and f32_split() and d in SPLIT_ATTENTION_HEAD_DIMS
 
 
-def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False):
+def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False, split_out=False):
     """q: [B, Nq, ldq] with Q in columns [0, H*D); k: [B, Nk, ldk] with K in columns [k_col, k_col+H*D)
-    (q and k may be the same fused-projection buffer); vt: [B, H*D, ldvt] (V transposed, keys contiguous)."""
+    (q and k may be the same fused-projection buffer); vt: [B, H*D, ldvt] (V transposed, keys contiguous).
+    ``split_out`` (float32 matrix-core mode): store O pre-split for the out-projection (the result carries the mark, is_asplit)."""
     _dev(q, k, vt)
     B, nq = q.shape[0], q.shape[1]
     hd = vt.shape[1]
@@ -511,8 +512,10 @@ def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False):
         if not (f32_split() and d in SPLIT_ATTENTION_HEAD_DIMS):
             raise HipExtensionError("attention: float32 runs on the split (three float16 products) kernel, head dims 40/64/80/160, "
                                     "in F32_MODE 'split' only; the exact float32 path composes gemm_nt + softmax_rows")
-        code = GMD_F32S
+        so = bool(split_out) and want_split_out(q.dtype, hd)
+        code = GMD_F32SA if so else GMD_F32S
     else:
+        so = False
         code = dtype_code(q.dtype)
     tm = profiling.active()
     tm = tm if tm is not None and tm.wants("attention") else None
@@ -522,7 +525,7 @@ def attention(q, k, vt, heads, nk, scale, k_col=0, causal=False):
                               float(scale), int(bool(causal)), _stream()), "gmd_attention")
     if tm:  # QK^T + PV, algorithmic head dim (padding not counted)
         tm.end("attention", 4.0 * B * nq * nk * hd, (2 * B * nq * hd + 2 * B * nk * hd) * q.element_size(), t0)
-    return o
+    return _mark_asplit(o) if so else o
 
 
 def softmax_rows(s, cols, scale, out_dtype, ldp=None, causal_nq=0):

@@ -652,6 +652,17 @@ def test_producers_store_the_presplit_activation_layout():
     bf = torch.randn(5120, generator=g).to(DEV)
     f, fs = o.gemm_nt(a, wf, bias=bf, act=o.ACT_GEGLU), o.gemm_nt(a, wf, bias=bf, act=o.ACT_GEGLU, split_out=True)
     assert o.is_asplit(fs) and torch.equal(as_bytes(fs), as_bytes(o.split_activation(f)))
+    # float32 attention epilogue (self-attention on a fused q|k buffer, d = 40; cross-attention with 77 keys, d = 80)
+    for (Bq, Nq, Nk, heads, d, fused) in [(2, 1024, 1024, 8, 40, True), (2, 256, 77, 8, 80, False)]:
+        C2 = heads * d
+        if fused:
+            qk = torch.randn(Bq, Nq, 2 * C2, generator=g).to(DEV)
+            q_, k_, kc = qk, qk, C2
+        else:
+            q_, k_, kc = torch.randn(Bq, Nq, C2, generator=g).to(DEV), torch.randn(Bq, Nk, C2, generator=g).to(DEV), 0
+        vt = torch.randn(Bq, C2, (Nk + 3) // 4 * 4, generator=g).to(DEV)
+        oa, os_ = o.attention(q_, k_, vt, heads, Nk, d ** -0.5, k_col=kc), o.attention(q_, k_, vt, heads, Nk, d ** -0.5, k_col=kc, split_out=True)
+        assert o.is_asplit(os_) and torch.equal(as_bytes(os_), as_bytes(o.split_activation(oa)))
     # a launch whose plan cannot write the layout returns the plain tensor, unmarked
     small = o.gemm_nt(a[:96], wf, bias=bf, act=o.ACT_GEGLU, split_out=True)
     assert not o.is_asplit(small) and torch.equal(small, f[:96])
