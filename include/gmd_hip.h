@@ -51,7 +51,8 @@ extern "C" {
  * [hi 64 B | lo 64 B] in the order of gmd_split_weights.  As `dtype` of gmd_gemm_nt / gmd_conv3x3(_groupnorm): the A operand AND W are
  * pre-split (no conversion instruction in the main loop; results bit-identical to GMD_F32SW on the plain tensor).  As `out_dtype` of
  * gmd_gemm_nt (GEGLU and plain row epilogues of the split types) and as `dtype` of gmd_layernorm / gmd_groupnorm_colstats /
- * gmd_groupnorm_split: float32 tensors in, the OUTPUT stored pre-split (rows must be multiples of 32 elements).  Such a tensor is
+ * gmd_groupnorm_split / gmd_attention (there: Q, K, V^T plain as for GMD_F32S): float32 tensors in, the OUTPUT stored pre-split (rows
+ * must be multiples of 32 elements, the buffer contiguous).  Such a tensor is
  * only ever an A (or W) operand of a contraction: nothing else reads it. */
 #define GMD_F32SA 5
 
