@@ -25,6 +25,7 @@ int gmd_launch_split_conv(const void* params, int presplit, int B, void* ws, int
 int gmd_split_plan_ksplit(int M, int N, int K, int64_t ws_bytes);
 int gmd_split_colstats_ok(int M, int N, int K, int batch, int64_t ws_bytes, int bucket);
 int gmd_split_out_ok(int M, int N, int K, int geglu, int64_t ws_bytes);
+int gmd_split_qkv_vt_ok(int M, int N, int K, int vt_col0, int vt_tokens, int64_t ws_bytes);
 void gmd_split_set_lc(int mode);
 
 namespace {
@@ -214,10 +215,51 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
 // residual (16-byte loads, same shape) and activation are applied on the way out in float32, bit-identical to the
 // register epilogue.  Caller guarantees: block tile fully inside M x N, ldc / ldr / batch strides multiples of 8, and a
 // __syncthreads() between the last LDS read of the K loop and this call.
+// The V column tiles of a fused Q|K|V projection (GemmParams::vt_out): the wave tile leaves TRANSPOSED -- lane = column, 32 rows
+// (tokens) per pass through the strip, packed to 64 contiguous bytes of vt_out[sample][column][token ...]: the layout the attention
+// kernels consume, written by the projection itself instead of by a second (batched, transposed) GEMM launch per attention.
+// alpha and bias as epilogue_rows; no residual / row bias / activation (host-checked).  Wave tiles never straddle a sample
+// (vt_tokens is a multiple of the wave tile's rows: host-checked).
+template <typename HT, int TM, int TN>
+__device__ __forceinline__ void epilogue_cols_vt(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane) {
+    constexpr int NCOL = TN * 16, ROWF = NCOL + 4;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int b = mw / p.vt_tokens, tok0 = mw - b * p.vt_tokens;
+#pragma unroll
+    for (int h = 0; h < TM / 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + j * 16 + fq * 4) =
+                    make_float4(acc[2 * h + i2][j][0], acc[2 * h + i2][j][1], acc[2 * h + i2][j][2], acc[2 * h + i2][j][3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+            const int cc = lane + 64 * k < NCOL ? lane + 64 * k : NCOL - 1;  // every lane reads (the idle ones the last column): no EXEC change
+            const float bz = p.bias ? p.bias[nw + cc] : 0.f;
+            unsigned pk[16];
+#pragma unroll
+            for (int r = 0; r < 32; r += 2)
+                pk[r / 2] = Half<HT>::pack2(strip[r * ROWF + cc] * p.alpha + bz, strip[(r + 1) * ROWF + cc] * p.alpha + bz);
+            if (lane + 64 * k < NCOL) {
+                HT* o = (HT*)p.vt_out + ((int64_t)b * (p.N - p.vt_col0) + (nw + cc - p.vt_col0)) * p.vt_ld + tok0 + h * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(o + 8 * q) = make_uint4(pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <typename HT, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
                                               int z) {
     static_assert(TM % 2 == 0, "halves of two 16-row tiles");
+    if (p.vt_out && nw >= p.vt_col0) {  // wave-uniform: a V column tile of a fused Q|K|V projection
+        epilogue_cols_vt<HT, TM, TN>(p, acc, strip, mw, nw, lane);
+        return;
+    }
     constexpr int NCOL = TN * 16, ROWF = NCOL + 4, CH = NCOL / 8;
     constexpr int ITER = (32 * CH + 63) / 64;
     const int frow = lane & 15, fq = lane >> 4;
@@ -2287,11 +2329,22 @@ int pick_tile_group(const Plan& pl, int M, int N, int K) {
     return g < 1 ? 1 : g;
 }
 
+// fused Q|K|V projection with transposed V tiles (GemmParams::vt_out, epilogue_cols_vt): every tile full and through the row epilogue,
+// the V columns starting on a tile boundary, wave tiles (64 or 32 rows) inside one sample
+bool qkv_vt_plan_ok(const Plan& pl, int M, int N, int batch, int vt_col0, int vt_tokens) {
+    return batch == 1 && pl.ksplit == 1 && M % pl.bm == 0 && N % pl.bn == 0 && vt_col0 > 0 && vt_col0 < N && vt_col0 % pl.bn == 0 &&
+           vt_tokens > 0 && vt_tokens % 64 == 0 && M % vt_tokens == 0;
+}
+
 template <typename HT, bool CONV>
 int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     constexpr bool kTune = std::is_same<HT, bf16_t>::value;
     hipError_t e = hipSuccess;
     const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
+    if (p.vt_out && !qkv_vt_plan_ok(pl, p.M, p.N, batch, p.vt_col0, p.vt_tokens)) {
+        gmd_set_error("%s: plan %dx%d ksplit=%d cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok first)", name, pl.bm, pl.bn, pl.ksplit);
+        return GMD_ERR_UNSUPPORTED;
+    }
     if (const char* why = plan_unsupported(pl, p, batch)) {
         gmd_set_error("%s: plan %dx%d pf=%d ksplit=%d (M=%d N=%d bucket=%d) %s", name, pl.bm, pl.bn, pl.pf, pl.ksplit, p.M, p.N, p.cs_bucket, why);
         return GMD_ERR_UNSUPPORTED;
@@ -2430,6 +2483,39 @@ int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t worksp
 
 // 1 when a float32-split gmd_gemm_nt launch of these dimensions can take out_dtype = GMD_F32SA (store its result pre-split)
 int gmd_gemm_out_split_ok(int M, int N, int K, int geglu, int64_t workspace_bytes) { return gmd_split_out_ok(M, N, K, geglu, workspace_bytes); }
+
+int gmd_gemm_qkv_vt_ok(int dtype, int M, int N, int K, int vt_col0, int vt_tokens, int64_t workspace_bytes) {
+    if (dtype == GMD_F32SW || dtype == GMD_F32SA) return gmd_split_qkv_vt_ok(M, N, K, vt_col0, vt_tokens, workspace_bytes);
+    if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % 64) return 0;
+    return qkv_vt_plan_ok(make_plan(M, N, K, 1, workspace_bytes, false), M, N, 1, vt_col0, vt_tokens) ? 1 : 0;
+}
+
+int gmd_gemm_qkv_vt(const void* A, const void* W, void* C, void* Vt, int dtype, int M, int N, int K, int64_t ldc, int vt_col0, int vt_tokens,
+                    int64_t vt_ld, float alpha, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+    const bool split = dtype == GMD_F32SW || dtype == GMD_F32SA;  // float32 tensors on the matrix cores, pre-split weights
+    GMD_REQUIRE(gmd_is_half(dtype) || split, "gmd_gemm_qkv_vt: the 16-bit types and GMD_F32SW / GMD_F32SA only (dtype %d)", dtype);
+    GMD_REQUIRE(M > 0 && N > 0 && K > 0 && K % (split ? 32 : 64) == 0, "gmd_gemm_qkv_vt: bad shape M=%d N=%d K=%d", M, N, K);
+    GMD_REQUIRE(A && W && C && Vt && gmd_aligned16(A) && gmd_aligned16(W) && gmd_aligned16(C) && gmd_aligned16(Vt), "gmd_gemm_qkv_vt: null or unaligned pointer");
+    GMD_REQUIRE(vt_col0 > 0 && vt_col0 < N && ldc >= vt_col0 && ldc % 8 == 0 && vt_tokens > 0 && M % vt_tokens == 0 && vt_ld >= vt_tokens && vt_ld % 8 == 0,
+                "gmd_gemm_qkv_vt: bad V geometry (vt_col0=%d ldc=%lld tokens=%d vt_ld=%lld)", vt_col0, (long long)ldc, vt_tokens, (long long)vt_ld);
+    GMD_REQUIRE(gmd_gemm_qkv_vt_ok(dtype, M, N, K, vt_col0, vt_tokens, workspace ? workspace_bytes : 0), "gmd_gemm_qkv_vt: this launch cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok)");
+    GemmParams p{};
+    p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = K; p.ldw = K; p.ldc = ldc;
+    {
+        const int es = split ? 4 : 2;
+        const int64_t ab = (int64_t)M * K * es, wb = (int64_t)N * K * es;
+        GMD_REQUIRE(ab < 0xFFFF0000LL && wb < 0xFFFF0000LL, "gmd_gemm_qkv_vt: operand slab larger than 4 GiB");
+        p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    }
+    p.rows_per_group = 1; p.ldrb = N; p.alpha = alpha; p.act = GMD_ACT_NONE; p.cblk = K;
+    p.vt_out = Vt; p.vt_col0 = vt_col0; p.vt_tokens = vt_tokens; p.vt_ld = vt_ld;
+    if (split) {
+        p.out_f32 = 1;
+        return gmd_launch_split_gemm(&p, dtype == GMD_F32SA ? 2 : 1, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_qkv_vt");
+    }
+    return launch<false>(p, dtype, 1, workspace, workspace_bytes, (hipStream_t)stream, "gmd_gemm_qkv_vt");
+}
 
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype, int M, int N, int K, int64_t lda,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,

@@ -42,6 +42,11 @@ struct GemmParams {
     // (m fastest inside a group, then the next N tile, then the next group); 1 = n fastest (the ring kernels' order).  Chosen on
     // the host so that what an XCD re-reads between reuses stays inside its 4 MiB L2 (gemm.hip: pick_tile_group).
     int tile_group;
+    // fused Q|K|V projection (gmd_gemm_qkv_vt): column tiles from vt_col0 on are the V columns and leave TRANSPOSED, as the
+    // attention kernels read them: vt_out[sample][column - vt_col0][token], row stride vt_ld, `vt_tokens` rows of C per sample
+    void* vt_out;
+    int vt_col0, vt_tokens;
+    int64_t vt_ld;
 };
 
 // (row tile, column tile) of linear tile index L under GemmParams::tile_group

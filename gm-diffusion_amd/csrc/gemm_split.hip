@@ -149,10 +149,47 @@ __device__ __forceinline__ void epilogue_regs_f32(const GemmParams& p, const f32
 // accumulators are parked in LDS, read back row-major and leave as 16-byte stores over whole 64*TN-byte row segments, the
 // residual read in the same shape.  SLAB: raw partial sums into this slice's split-K slab instead (no epilogue terms).
 // Strip rows are 16 rows at a time per TM tile pair: 32 rows x (TN*16 + 4) floats per wave.
+// float32 twin of epilogue_cols_vt (gemm.hip): a V column tile of a fused Q|K|V projection leaves transposed -- lane = column, 32 tokens
+// = 128 contiguous bytes of vt_out[sample][column][token ...] per pass
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_cols_vt_f32(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane) {
+    constexpr int NCOL = TN * 16, ROWF = NCOL + 4;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int b = mw / p.vt_tokens, tok0 = mw - b * p.vt_tokens;
+#pragma unroll
+    for (int h = 0; h < TM / 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + j * 16 + fq * 4) =
+                    make_float4(acc[2 * h + i2][j][0], acc[2 * h + i2][j][1], acc[2 * h + i2][j][2], acc[2 * h + i2][j][3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < (NCOL + 63) / 64; ++k) {
+            const int cc = lane + 64 * k < NCOL ? lane + 64 * k : NCOL - 1;  // every lane reads: no EXEC change around the loop
+            const float bz = p.bias ? p.bias[nw + cc] : 0.f;
+            float v[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) v[r] = strip[r * ROWF + cc] * p.alpha + bz;
+            if (lane + 64 * k < NCOL) {
+                float* o = (float*)p.vt_out + ((int64_t)b * (p.N - p.vt_col0) + (nw + cc - p.vt_col0)) * p.vt_ld + tok0 + h * 32;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int TM, int TN, bool SLAB>
 __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
                                                   int z, int ks) {
     static_assert(TM % 2 == 0, "halves of two 16-row tiles");
+    if (!SLAB && p.vt_out && nw >= p.vt_col0) {  // wave-uniform: a V column tile of a fused Q|K|V projection
+        epilogue_cols_vt_f32<TM, TN>(p, acc, strip, mw, nw, lane);
+        return;
+    }
     constexpr int NCOL = TN * 16, ROWF = NCOL + 4, CH = NCOL / 4;
     constexpr int ITER = (32 * CH + 63) / 64;
     const int frow = lane & 15, fq = lane >> 4;
@@ -952,6 +989,11 @@ int launch_split_any(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStr
             return GMD_ERR_UNSUPPORTED;
         }
     }
+    if (p.vt_out && !(pl.bm == 128 && pl.ksplit == 1 && batch == 1 && p.M % 128 == 0 && p.N % pl.bn == 0 && p.vt_col0 % pl.bn == 0 &&
+                      p.vt_tokens % 64 == 0 && (p.ldc & 3) == 0)) {
+        gmd_set_error("%s: this float32 launch cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok first)", name);
+        return GMD_ERR_UNSUPPORTED;
+    }
     if (p.c_split) {  // pre-split output: only the full-tile row epilogues write it (gmd_split_out_ok + their alignment conditions)
         const bool rows_ok = pl.bm == 128 && pl.ksplit == 1 && batch == 1 && p.M % 128 == 0 && p.N % pl.bn == 0 && (p.ldc & 3) == 0 &&
                              (p.residual == nullptr || (p.ldr & 3) == 0) &&
@@ -1014,6 +1056,13 @@ int gmd_split_out_ok(int M, int N, int K, int geglu, int64_t ws_bytes) {
     SplitPlan pl = make_split_plan(M, N, K, 1, ws_bytes);
     if (geglu) { if (pl.bn == 160) pl.bn = 128; pl.ksplit = 1; }
     return (pl.bm == 128 && pl.ksplit == 1 && M % 128 == 0 && N % pl.bn == 0) ? 1 : 0;
+}
+
+// fused Q|K|V projection with transposed V tiles on the float32 matrix-core path (GemmParams::vt_out)
+int gmd_split_qkv_vt_ok(int M, int N, int K, int vt_col0, int vt_tokens, int64_t ws_bytes) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 || vt_col0 <= 0 || vt_col0 >= N || vt_tokens <= 0 || vt_tokens % 64 || M % vt_tokens) return 0;
+    const SplitPlan pl = make_split_plan(M, N, K, 1, ws_bytes);
+    return (pl.bm == 128 && pl.ksplit == 1 && M % 128 == 0 && N % pl.bn == 0 && vt_col0 % pl.bn == 0) ? 1 : 0;
 }
 
 // split-K factor launch_split_any will choose (no GEGLU): gmd_conv3x3_groupnorm / gmd_conv3x3_gn_fusable of gemm.hip

@@ -46,6 +46,8 @@ SIGNATURES = {
     "gmd_gemm_colstats_plan": [I, I, I, I, I, L, I],
     "gmd_gemm_plan_info": [I, I, I, I, I, L, I, P],
     "gmd_gemm_out_split_ok": [I, I, I, I, L],
+    "gmd_gemm_qkv_vt_ok": [I, I, I, I, I, I, L],
+    "gmd_gemm_qkv_vt": [P, P, P, P, I, I, I, I, L, I, I, L, F, P, L, P],
     "gmd_conv_patch_override": [I],
     "gmd_stamp": [P, P, I, I, P],
     "gmd_split_weights": [P, P, L, L, L, P],

@@ -454,6 +454,8 @@ class UNet2DConditionModel(_HipModule):
                 q1, k1 = self._raw[f"{b}.attn1.to_q.weight"], self._raw[f"{b}.attn1.to_k.weight"]
                 blk["qk1"] = self._wt(torch.cat([q1, k1], 0))  # fused [2C, C] projection
                 blk["v1"] = self._wa(self._raw[f"{b}.attn1.to_v.weight"])
+                # q | k | v stacked: ONE launch writes Q|K row-major and V transposed (hip_ops.gemm_qkv_vt; 16-bit and float32 split modes)
+                blk["qkv1"] = self._wt(torch.cat([q1, k1, self._raw[f"{b}.attn1.to_v.weight"]], 0))
                 blk["o1"] = self._lin(f"{b}.attn1.to_out.0")
                 blk["q2"] = self._lin(f"{b}.attn2.to_q", False)[0]
                 blk["k2"] = self._lin(f"{b}.attn2.to_k", False)[0]
@@ -544,6 +546,11 @@ class UNet2DConditionModel(_HipModule):
         heads = t["heads"]
         d = C // heads
         scale = d ** -0.5
+        if "qkv1" in t and (ops.is_half(self._dtype) or ops.split_attention_ok(self._dtype, d)):
+            r = ops.gemm_qkv_vt(n1, t["qkv1"], 2 * C, N)
+            if r is not None:
+                qk = r[0].view(B, N, 2 * C)
+                return ops.attention(qk, qk, r[1], heads, N, scale, k_col=C, split_out=self._sa(t["o1"][0]))
         qk = ops.gemm_nt(n1, t["qk1"]).view(B, N, 2 * C)
         if ops.is_half(self._dtype) or ops.split_attention_ok(self._dtype, d):
             nv = n1.view(B, N, C)

@@ -22,7 +22,7 @@ from . import profiling
 from ._native import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, GMD_BF16, GMD_F16, GMD_F32, GMD_F32S, GMD_F32SA, GMD_F32SW, HipExtensionError, check, lib
 
 __all__ = [
-    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows", "set_f32_mode", "f32_split", "split_weights", "scale_weight", "split_attention_ok", "ff_fused_ok", "ff_geglu_fused", "dup_batch",
+    "ACT_NONE", "ACT_SILU", "ACT_GEGLU", "ACT_QUICK_GELU", "embedding_lookup", "dpm_step", "ddpm_step", "HipExtensionError", "dtype_code", "gemm_nt", "conv3x3", "attention", "softmax_rows", "set_f32_mode", "f32_split", "split_weights", "scale_weight", "split_attention_ok", "ff_fused_ok", "ff_geglu_fused", "gemm_qkv_vt", "dup_batch",
     "groupnorm_scale_shift", "groupnorm_apply", "groupnorm", "groupnorm_split", "layernorm", "geglu", "timestep_embedding",
     "concat_channels", "cast", "pack_unet_input", "unpack_nchw", "latent_step", "cfg_std_ratio", "hdr_tail",
     "apply_gm_to_sdr", "tmo", "gamut_compress", "stage1_chain", "discretize_u16", "quantize_u8",
@@ -377,6 +377,44 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
     if c_split:
         _mark_asplit(out)
     return out
+
+
+# Fused Q|K|V projection of a self-attention: the V column tiles leave the projection TRANSPOSED (gmd_gemm_qkv_vt), so the batched
+# V^T GEMM of every attention disappears.  GMD_QKV_VT=0 keeps the two launches (A/B measurements, tests).
+USE_QKV_VT = os.environ.get("GMD_QKV_VT", "1") != "0"
+
+
+def gemm_qkv_vt(a, w, vt_col0, tokens):
+    """a: [B*tokens, K] (16-bit, or float32 with pre-split weights), w: [N, K] = the stacked q | k | v projection weights.  Returns (qk [B*tokens, vt_col0],
+    vt [B, N - vt_col0, tokens]) from ONE launch, or None when this launch's plan cannot write transposed V tiles (the caller then
+    runs the two projections separately)."""
+    _dev(a, w)
+    M, K = a.shape
+    N = w.shape[0]
+    if not (USE_QKV_VT and a.dtype == w.dtype and a.dim() == 2 and w.dim() == 2 and w.shape[1] == K and tokens % 64 == 0 and M % tokens == 0
+            and vt_col0 % 8 == 0):
+        return None
+    if is_half(a.dtype):
+        if K % 64:
+            return None
+        code = dtype_code(a.dtype)
+    else:  # float32 on the matrix cores: pre-split weights (and, with the pre-split activation format, a pre-split A operand)
+        if not (a.dtype == torch.float32 and getattr(w, "_split", False) and K % 32 == 0):
+            return None
+        code = GMD_F32SA if is_asplit(a) else GMD_F32SW
+    if not lib().gmd_gemm_qkv_vt_ok(code, M, N, K, vt_col0, tokens, WORKSPACE_BYTES):
+        return None
+    qk = torch.empty((M, vt_col0), dtype=a.dtype, device=a.device)
+    vt = torch.empty((M // tokens, N - vt_col0, tokens), dtype=a.dtype, device=a.device)
+    ws = _workspace(a.device)
+    tm = profiling.active()
+    tm = tm if tm is not None and tm.wants("gemm_nt") else None
+    t0 = tm.begin() if tm else None
+    check(lib().gmd_gemm_qkv_vt(_ptr(a), _ptr(w), _ptr(qk), _ptr(vt), code, M, N, K, vt_col0, vt_col0, tokens, tokens,
+                                float(getattr(w, "_alpha", 1.0)), _ptr(ws), WORKSPACE_BYTES, _stream()), "gmd_gemm_qkv_vt")
+    if tm:
+        tm.end("gemm_nt", 2.0 * M * N * K, (M * K + N * K + M * N) * a.element_size(), t0)
+    return qk, vt
 
 
 # The GEGLU feed-forward as one launch (csrc/ff_fused.hip) where the kernel is instantiated; GMD_FUSED_FF=0 keeps the two

@@ -236,6 +236,16 @@ int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t wo
  * it to know what they exercise; nothing in the product path calls it.  Returns GMD_ERR_INVALID for other element types. */
 int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4);
 
+/* Fused Q|K|V projection of a self-attention (round 4, 16-bit types): C[M, vt_col0] (row stride ldc) = alpha * A[M,K] W[0:vt_col0, K]^T as
+ * gmd_gemm_nt writes it, and the remaining N - vt_col0 columns (the V projection) TRANSPOSED, the way gmd_attention reads V:
+ * Vt[sample][column - vt_col0][token] with row stride vt_ld, `vt_tokens` consecutive rows of A per sample.  One launch instead of the
+ * projection plus a batched transposed GEMM per attention.  gmd_gemm_qkv_vt_ok: 1 when the launch's plan can do it (full tiles, the V
+ * columns on a tile boundary, vt_tokens a multiple of 64); otherwise use gmd_gemm_nt twice.
+ * reference: Attention.to_q / to_k / to_v of diffusers as called at gm_diffusion/pipelines/stable_diffusion_dual_unet.py:1052 */
+int gmd_gemm_qkv_vt_ok(int dtype, int M, int N, int K, int vt_col0, int vt_tokens, int64_t workspace_bytes);
+int gmd_gemm_qkv_vt(const void* A, const void* W, void* C, void* Vt, int dtype, int M, int N, int K, int64_t ldc, int vt_col0, int vt_tokens,
+                    int64_t vt_ld, float alpha, void* workspace, int64_t workspace_bytes, gmd_stream_t stream);
+
 /* 1 when a float32-split gmd_gemm_nt launch of these dimensions (batch 1) can take out_dtype = GMD_F32SA, i.e. store its [M, N] (GEGLU:
  * [M, N/2]) result pre-split for the contraction that follows: an unsplit launch of full 128-row tiles through the row epilogues. */
 int gmd_gemm_out_split_ok(int M, int N, int K, int geglu, int64_t workspace_bytes);

@@ -330,3 +330,62 @@ def test_grouped_tile_orders_cover_every_tile_once(M, N, K, geglu, force_plan):
             y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
             ops.gemm_nt(a, w, bias=b, out=y)
             assert torch.isfinite(y).all() and _rel(y, a.double() @ w.double().T + b.double()) < 4e-3
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,tokens,C", [(8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (4, 4096, 320), (4, 1024, 640), (4, 256, 1280), (8, 64, 1280), (2, 64, 1280)])
+def test_fused_qkv_projection_writes_v_transposed(dt, B, tokens, C):
+    """gmd_gemm_qkv_vt (round 4): ONE launch gives Q|K row-major and V transposed ([B, C, tokens], what gmd_attention reads) -- against the
+    two launches it replaces (fused q|k projection + batched V^T GEMM) and against float64.  Where the plan cannot write transposed
+    tiles the op says so (None) and the caller keeps the two launches."""
+    from gm_diffusion import hip_ops as o
+    from gm_diffusion._native import lib
+
+    g = torch.Generator().manual_seed(B + tokens + C)
+    n = torch.randn(B * tokens, C, generator=g).to(DEV, dt)
+    wq, wk, wv = ((torch.randn(C, C, generator=g) * C ** -0.5).to(DEV, dt) for _ in range(3))
+    r = o.gemm_qkv_vt(n, torch.cat([wq, wk, wv], 0).contiguous(), 2 * C, tokens)
+    qk_ref = o.gemm_nt(n, torch.cat([wq, wk], 0).contiguous())
+    vt_ref = o.gemm_nt(wv, n.view(B, tokens, C), ldc=tokens)
+    if r is None:
+        assert not lib().gmd_gemm_qkv_vt_ok(o.dtype_code(dt), B * tokens, 3 * C, C, 2 * C, tokens, o.WORKSPACE_BYTES)
+        return
+    qk, vt = r
+    assert qk.shape == qk_ref.shape and vt.shape == vt_ref.shape == (B, C, tokens)
+    vd = (wv.double() @ n.double().view(B, tokens, C).transpose(1, 2))
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+    assert float((vt.double() - vd).abs().max()) <= tol * float(vd.abs().max())
+    # the same products in the same K order as the launches it replaces: equal up to the rounding of one ulp where a tile shape differs
+    assert float((qk.float() - qk_ref.float()).abs().max()) <= tol * float(qk_ref.float().abs().max())
+    assert float((vt.float() - vt_ref.float()).abs().max()) <= tol * float(vt_ref.float().abs().max())
+    print(f"qkv {dt} B={B} tokens={tokens} C={C}: bit-identical to the two launches: qk {bool(torch.equal(qk, qk_ref))} vt {bool(torch.equal(vt, vt_ref))}")
+
+
+@pytest.mark.parametrize("B,tokens,C,presplit_a", [(8, 4096, 320, True), (8, 1024, 640, False), (8, 256, 1280, True), (4, 1024, 640, True), (8, 64, 1280, False)])
+def test_fused_qkv_projection_float32_matrix_core_path(B, tokens, C, presplit_a):
+    """The same launch on the float32 path (three float16 passes, pre-split stacked weight; optionally a pre-split activation operand):
+    Q|K and V^T against float64 at float32 grade."""
+    from gm_diffusion import hip_ops as o
+    from gm_diffusion._native import lib
+
+    prev = o.set_f32_mode("split")
+    try:
+        g = torch.Generator().manual_seed(B + tokens + C)
+        n = torch.randn(B * tokens, C, generator=g).to(DEV)
+        w = (torch.randn(3 * C, C, generator=g) * C ** -0.5).to(DEV)
+        a = o.split_activation(n) if presplit_a else n
+        r = o.gemm_qkv_vt(a, o.split_weights(w), 2 * C, tokens)
+        if r is None:
+            assert not lib().gmd_gemm_qkv_vt_ok(4, B * tokens, 3 * C, C, 2 * C, tokens, o.WORKSPACE_BYTES)
+            return
+        qk, vt = r
+        ref = n.double() @ w.double().t()
+        e1 = float((qk.double() - ref[:, :2 * C]).norm() / ref[:, :2 * C].norm())
+        vd = ref[:, 2 * C:].view(B, tokens, C).transpose(1, 2)
+        e2 = float((vt.double() - vd).norm() / vd.norm())
+        assert vt.shape == (B, C, tokens) and e1 < 1.5e-6 and e2 < 1.5e-6, (e1, e2)
+        # the plain and the pre-split activation operand give the same bits
+        r2 = o.gemm_qkv_vt(n if presplit_a else o.split_activation(n), o.split_weights(w), 2 * C, tokens)
+        assert torch.equal(r2[0], qk) and torch.equal(r2[1], vt)
+    finally:
+        o.set_f32_mode(prev)
