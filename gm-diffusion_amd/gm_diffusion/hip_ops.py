@@ -376,6 +376,8 @@ def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alph
         del out._colstats
     if c_split:
         _mark_asplit(out)
+    elif getattr(out, "_asplit", False):  # a reused `out=` buffer must not keep an earlier launch's layout mark
+        del out._asplit
     return out
 
 
