@@ -44,6 +44,7 @@ constexpr float kNegBig = -1.0e30f;
 template <typename HT, int D, bool CAUSAL>  // HT: bf16_t or f16_t (storage pointers stay raw 16-bit)
 // d <= 40: four waves per SIMD (128 VGPRs), d <= 64: three (<= 168) -- the softmax VALU of one wave hides under the MFMAs of the others
 __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd_kernel(const AttnParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_ATTN);
     constexpr int DK = (D + 15) / 16;         // 16-wide k-steps of Q K^T over d
     constexpr int DT = (D + 31) / 32;         // 32-row tiles of O^T over d
     constexpr int KROW = (2 * DK + 1) * 16;   // bytes per K LDS row: odd number of 16-byte slots
@@ -451,6 +452,7 @@ template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatil
 
 template <typename HT>
 __global__ __launch_bounds__(256, 4) void attn40_kernel(const AttnParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_ATTN40);
     constexpr int D = 40, DK = 3, DT = 2, NST = 3;
     constexpr int KROWB = 2 * D;                 // dense K row, bytes
     constexpr int kLagOff = KV * KROWB;          // {1.0, 0 x 7}
@@ -867,3 +869,5 @@ extern "C" int gmd_attention(const void* Q, const void* K, const void* Vt, void*
     hipStream_t s = (hipStream_t)stream;
     return dtype == GMD_F16 ? dispatch_attn<f16_t>(p, B, H, D, Nq, Nk, causal, s) : dispatch_attn<bf16_t>(p, B, H, D, Nq, Nk, causal, s);
 }
+
+GMD_WG_TRACE_SETTER(attention)

@@ -11,6 +11,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void geglu_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int F) {
+    GMD_WG_TRACE_SCOPE(WGK_OTHER);
     constexpr int V = Elem<T>::kVec;
     const int FV = F / V;
     const int64_t total = rows * FV;
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(kThreads) void geglu_kernel(const T* __restrict__ X
 // diffusers get_timestep_embedding: emb_i = t * exp(-ln(10000) * i / (half - shift)); [sin | cos], flipped to [cos | sin]
 template <typename T>
 __global__ void temb_kernel(const float* __restrict__ t_dev, T* __restrict__ out, int B, int dim, int flip, float shift) {
+    GMD_WG_TRACE_SCOPE(WGK_TEMB);
     const int half = dim / 2;
     const float t = *t_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * half; i += gridDim.x * blockDim.x) {
@@ -45,6 +47,7 @@ __global__ void temb_kernel(const float* __restrict__ t_dev, T* __restrict__ out
 template <typename T>
 __global__ __launch_bounds__(kThreads) void concat_kernel(const T* __restrict__ A, int Ca, const T* __restrict__ Bm, int Cb,
                                                           T* __restrict__ out, int64_t rows) {
+    GMD_WG_TRACE_SCOPE(WGK_CONCAT);
     constexpr int V = Elem<T>::kVec;
     const int CV = (Ca + Cb) / V, CaV = Ca / V;
     const int64_t total = rows * CV;
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(kThreads) void concat_kernel(const T* __restrict__ 
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(kThreads) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+    GMD_WG_TRACE_SCOPE(WGK_CAST);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         Elem<TO>::st(out + i, Elem<TI>::ld(in + i));
 }
@@ -69,6 +73,7 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void embedding_kernel(const int32_t* __restrict__ ids, const T* __restrict__ table,
                                                              const T* __restrict__ pos, T* __restrict__ out, int64_t rows, int Tn, int C,
                                                              int vocab) {
+    GMD_WG_TRACE_SCOPE(WGK_OTHER);
     const int64_t total = rows * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / C;
@@ -91,6 +96,7 @@ inline int grid_for(int64_t n) {
 // writes per chunk; the runtime's generic device-to-device copy took 2 x 83 us for the 2 x 10.5 MB of a level-0 tensor inside
 // the two-stream pipeline (rocprofv3, profiles/r03_*), this kernel streams it at the HBM rate.
 __global__ __launch_bounds__(kThreads) void dup_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t n) {
+    GMD_WG_TRACE_SCOPE(WGK_DUP);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint4 v = in[i];
         out[i] = v;
@@ -203,6 +209,7 @@ int gmd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, 
 // ------------------------------------------------------------------------------------------------
 namespace {
 __global__ void stamp_kernel(unsigned long long* base, const int* row, int stride, int k) {
+    GMD_WG_TRACE_SCOPE(WGK_STAMP);
     unsigned long long t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     base[(row ? (long long)*row * stride : 0) + k] = t;
@@ -215,3 +222,18 @@ extern "C" int gmd_stamp(uint64_t* base, const int* row, int stride, int k, gmd_
     GMD_CHECK_LAUNCH("gmd_stamp");
     return GMD_OK;
 }
+
+GMD_WG_TRACE_SETTER(elementwise)
+#ifdef GMD_WG_TRACE
+// Diagnostic build only (not part of the product ABI): point every translation unit's trace hook at `ring` (a GmdWgTraceHeader followed
+// by capacity x 32-byte records, zeroed by the caller; nullptr switches the trace off).  Not stream-ordered: call it with the device idle.
+extern "C" int gmd_wg_trace_set_gemm(void*);
+extern "C" int gmd_wg_trace_set_attention(void*);
+extern "C" int gmd_wg_trace_set_norm(void*);
+extern "C" int gmd_wg_trace_set_ff_fused(void*);
+extern "C" int gmd_wg_trace_set_latent_step(void*);
+extern "C" int gmd_wg_trace_enable(void* ring) {
+    return gmd_wg_trace_set_gemm(ring) | gmd_wg_trace_set_attention(ring) | gmd_wg_trace_set_norm(ring) | gmd_wg_trace_set_ff_fused(ring) |
+           gmd_wg_trace_set_latent_step(ring) | gmd_wg_trace_set_elementwise(ring);
+}
+#endif

@@ -37,6 +37,7 @@ struct FFParams {
 
 template <typename HT, int C>
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_FF_FUSED);
     constexpr int BM = 128, CH = 128;               // token rows per workgroup, hidden units per chunk
     constexpr int N1 = 2 * CH;                      // interleaved value | gate columns per chunk
     constexpr int K1 = C / BK, K2 = CH / BK;        // K steps of the first / second product per chunk
@@ -258,3 +259,5 @@ extern "C" int gmd_ff_geglu_fused(const void* X, const void* W1i, const float* b
     p.x_bytes = (unsigned)(M * C * 2); p.w1_bytes = (unsigned)(8 * C * C * 2); p.w2_bytes = (unsigned)(C * 4 * C * 2);
     return dtype == GMD_F16 ? launch_ff<f16_t, 320>(p, (hipStream_t)stream) : launch_ff<bf16_t, 320>(p, (hipStream_t)stream);
 }
+
+GMD_WG_TRACE_SETTER(ff_fused)

@@ -74,6 +74,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
 // split-K: sum the fp32 partial slabs ws[s][m][n] in a fixed order, then the fused epilogue
 template <typename HT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_SPLITK_REDUCE);
     const int NC = (p.N + 7) / 8;
     const int64_t total = (int64_t)p.M * NC;
     const int64_t slab = (int64_t)p.M * p.N;
@@ -415,6 +416,7 @@ __device__ __forceinline__ void epilogue_rows_geglu(const GemmParams& p, const f
 // tile kt and are written to LDS at the end of iteration kt+PF-1, i.e. they have PF whole iterations to land.
 template <typename HT, bool CONV, int BM, int BN, int PF>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_GEMM64 | (CONV ? WGK_CONV_BIT : 0));
     constexpr int NA = BM / 32, NW = BN / 32;  // staging slots per thread
     constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave along M / N (wave tile = BM/2 x BN/2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 
 template <typename HT, bool CONV, int WM, int WN, int TN, int NST>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) void gemm_ring_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_RING | (CONV ? WGK_CONV_BIT : 0));
     constexpr int NWAVES = WM * WN, TM = 4;
     constexpr int BM = WM * 64, BN = WN * TN * 16;
     constexpr int RPP = NWAVES * 8;                 // tile rows written per staging pass (8 rows per wave instruction)
@@ -928,6 +931,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
 // ------------------------------------------------------------------------------------------------
 template <typename HT, bool CONV, int TN>
 __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_PP | (CONV ? WGK_CONV_BIT : 0));
     constexpr int WN = 2, NCONS = 8, LW = 4, TM = 4, NST = 3;
     constexpr int BM = 256, BN = WN * TN * 16;
     constexpr int RPP = LW * 8;                     // 32 tile rows per staging pass (8 rows per loader-wave instruction)
@@ -1249,6 +1253,7 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 template <typename HT, bool CONV, int TM, int TN>
 __global__ __launch_bounds__(512, 2) void gemm_lc_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_LC | (CONV ? WGK_CONV_BIT : 0));
     constexpr int WN = 2, NCONS = 4, LW = 4, NST = 4;
     constexpr int BM = 2 * TM * 16, BN = WN * TN * 16;
     constexpr int RPP = LW * 8;                     // 32 tile rows per staging pass
@@ -1499,6 +1504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lc_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 template <typename HT, int TN, int NPP>
 __global__ __launch_bounds__(768, 3) void conv_patch_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_PATCH | WGK_CONV_BIT);
     constexpr int WN = 2, NCONS = 8, LW = 4, TM = 4, NWS = 3;
     constexpr int BM = 256, BN = WN * TN * 16;
     constexpr int NWP = BN / (LW * 8);               // W pieces per loader wave and K step (5 / 4)
@@ -1738,6 +1744,7 @@ __global__ __launch_bounds__(768, 3) void conv_patch_kernel(const GemmParams p) 
 // ~130 cycles of barrier skew in each of its four intervals per K step: tools/pp_diag.py.)
 template <typename HT, int TN, int NPP>
 __global__ __launch_bounds__(768, 3) void conv_patch_cont_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_PATCH_CONT | WGK_CONV_BIT);
     constexpr int WN = 2, NCONS = 8, LW = 4, TM = 4, NWS = 3;
     constexpr int BM = 256, BN = WN * TN * 16;
     constexpr int NWP = BN / (LW * 8);               // W pieces per loader wave and K step (5 / 4)
@@ -1960,6 +1967,7 @@ __global__ __launch_bounds__(768, 3) void conv_patch_cont_kernel(const GemmParam
 // ------------------------------------------------------------------------------------------------
 template <bool CONV>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    GMD_WG_TRACE_SCOPE(WGK_GEMM_F32);
     constexpr int BM = 64, BN = 64, FK = 16, LD = 68;
     __shared__ __attribute__((aligned(16))) float As[FK][LD];
     __shared__ __attribute__((aligned(16))) float Ws[FK][LD];
@@ -2079,8 +2087,13 @@ const bool g_pp_enabled = [] { const char* e = getenv("GMD_PP"); return !(e && e
 // runs and tests (GMD_TUNING=1 only).  Whole-run A/B (profiles/r04_ab_bench_plan_families.txt): 838.7 / 840.6 / 837.5 ms for 0 / 1 / 2
 // -- level by time, but the patch forms pull half the bytes from L2 (25.6 instead of 52 KB per K step).
 int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
-// A/B only: GMD_PP=b selects 256-row tiles with K slices everywhere (see make_plan)
-const bool g_big_tiles = [] { const char* e = getenv("GMD_PP"); return e && e[0] == 'b'; }();
+// Plan family (round 5, see make_plan): 0 = the plan that is fastest launch by launch when the launch has the chip to itself (direct
+// calls, single-stream pipelines, the VAE); 1 = the co-running family -- 256-row tiles everywhere, filled up with K slices -- for
+// launches that share the chip with a second stream's kernels (the dual-UNet pipeline's two forwards).  The calling thread selects
+// it with gmd_gemm_plan_family(); GMD_PP=b / GMD_PP=1 pin family 1 / 0 for the whole process (A/B runs), read once at load time.
+const int g_family_pin = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b') ? 1 : ((e && e[0] == '1') ? 0 : -1); }();
+thread_local int t_plan_family = 0;
+inline bool big_tiles() { return (g_family_pin >= 0 ? g_family_pin : t_plan_family) == 1; }
 
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
@@ -2137,17 +2150,18 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
     //     640->640 at batch 8 72.8 -> 55.5 us, 64x64 320->320 at batch 4 41.3 -> 33.0 us, linear M=2048 N=1280 K=5120 49.4 -> 36.8 us.
     //     More than 256 such tiles would run in two rounds of one workgroup per CU, fewer than ~200 leave CUs idle: both keep the
     //     plans above.
-    // ALTERNATIVE (GMD_PP=b) -- the largest tile, filled up with K slices: slower launch by launch, but 0.4...1.3 % faster on the wall
-    // of the two-stream pipeline in three interleaved whole-run A/B comparisons (profiles/r04_ab_bench_plan_families.txt: 828.1 vs
-    // 838.7, 838.7 vs 845.2, 861.7 vs 864.8 ms per batch; round-3 plans 851.6 / 849.6 / 858.8).  With two streams in flight a second
+    // CO-RUNNING FAMILY (gmd_gemm_plan_family(1); what the dual-UNet pipeline selects for its two overlapped forwards) -- the largest
+    // tile, filled up with K slices: slower launch by launch, faster on the wall of the two-stream pipeline in every interleaved
+    // whole-run A/B (profiles/r05_ab_plan_default.txt, five rounds on one box: 867.7 -> 849.0 ms per batch at batch 4 (-2.2 %, 5 of 5),
+    // 1454.3 -> 1436.9 at batch 8 (-1.2 %, 3 of 3); round 4, three boxes: -0.4 ... -1.3 %).  With two streams in flight a second
     // workgroup is always there to hide a kernel's own latencies, so L2 -> LDS bytes per product -- (1/BM + 1/BN) x 2 B: 0.020 for a
-    // 256 x 160 tile, 0.028 for 128 x 160, 0.044 for 64 x 160 -- weigh more than the launch's time alone on the chip (streams
-    // serialised, the launch-by-launch plans win clearly: 1066 -> 1018 ms).  Not the default: the gain is inside the box-to-box
-    // spread, and single-stream users (the GM pipeline, the VAE, every direct call) would pay for it.  GMD_PP=0: the round-3 plans.
+    // 256 x 160 tile, 0.028 for 128 x 160, 0.044 for 64 x 160 -- weigh more than the launch's time alone on the chip.  With the
+    // streams serialised the same family LOSES 8.6 % (1018.3 -> 1106.3 ms), so it is never the choice of a launch that runs alone:
+    // family 0 stays the default of the C ABI.  GMD_PP=0: the round-3 plans.
     if (g_pp_enabled && batch == 1 && !(fbm && fbn) && !fpf && !fks && M >= 64) {
         const int64_t mt256 = (M + 255) / 256;
         const int bn = N % 160 == 0 ? 160 : (N % 128 == 0 ? 128 : 0);
-        if (g_big_tiles) {
+        if (big_tiles()) {
             if (pair_tiles) {
                 if (M >= 256 && N % 128 == 0) pl = Plan{256, 128, 283, 1};  // GEGLU pairs value / gate tiles: no K slices
             } else if (bn && M >= 256) {
@@ -2458,6 +2472,12 @@ int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit) {
     return GMD_OK;
 }
 
+int gmd_gemm_plan_family(int family) {
+    const int prev = t_plan_family;
+    if (family == 0 || family == 1) t_plan_family = family;  // anything else: query only
+    return prev;
+}
+
 int gmd_conv_patch_override(int mode) {
     GMD_REQUIRE(mode >= 0 && mode <= 2, "gmd_conv_patch_override: mode 0, 1 or 2");
     if (!tuning_enabled()) {
@@ -2498,6 +2518,9 @@ int gmd_gemm_qkv_vt(const void* A, const void* W, void* C, void* Vt, int dtype, 
     GMD_REQUIRE(A && W && C && Vt && gmd_aligned16(A) && gmd_aligned16(W) && gmd_aligned16(C) && gmd_aligned16(Vt), "gmd_gemm_qkv_vt: null or unaligned pointer");
     GMD_REQUIRE(vt_col0 > 0 && vt_col0 < N && ldc >= vt_col0 && ldc % 8 == 0 && vt_tokens > 0 && M % vt_tokens == 0 && vt_ld >= vt_tokens && vt_ld % 8 == 0,
                 "gmd_gemm_qkv_vt: bad V geometry (vt_col0=%d ldc=%lld tokens=%d vt_ld=%lld)", vt_col0, (long long)ldc, vt_tokens, (long long)vt_ld);
+    // pre-split operands are [hi 64 B | lo 64 B] per 32-element chunk of a row (rows are K elements here): whole 128-byte chunks only
+    GMD_REQUIRE(!split || ((reinterpret_cast<uintptr_t>(W) & 127) == 0 && (dtype != GMD_F32SA || (reinterpret_cast<uintptr_t>(A) & 127) == 0)),
+                "gmd_gemm_qkv_vt: a pre-split operand must be 128-byte aligned (32-element chunks of [hi | lo])");
     GMD_REQUIRE(gmd_gemm_qkv_vt_ok(dtype, M, N, K, vt_col0, vt_tokens, workspace ? workspace_bytes : 0), "gmd_gemm_qkv_vt: this launch cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok)");
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K;
@@ -2539,6 +2562,14 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
     GMD_REQUIRE(lda % vec == 0 && ldw % vec == 0 && strideA % vec == 0 && strideW % vec == 0,
                 "gmd_gemm_nt: lda/ldw/strides must be multiples of %d elements", vec);
     GMD_REQUIRE(A && W && C && gmd_aligned16(A) && gmd_aligned16(W) && gmd_aligned16(C), "gmd_gemm_nt: null or unaligned pointer");
+    // A pre-split operand is [hi 64 B | lo 64 B] per 32-element chunk of a ROW: a leading dimension / batch stride that is not a
+    // whole number of chunks, or a view that starts inside a chunk, would be read as the wrong halves without any fault
+    if (dtype == GMD_F32SW || dtype == GMD_F32SA)
+        GMD_REQUIRE(ldw % 32 == 0 && strideW % 32 == 0 && (reinterpret_cast<uintptr_t>(W) & 127) == 0,
+                    "gmd_gemm_nt: a pre-split W operand needs ldw and strideW multiples of 32 elements and a 128-byte aligned base");
+    if (dtype == GMD_F32SA)
+        GMD_REQUIRE(lda % 32 == 0 && strideA % 32 == 0 && (reinterpret_cast<uintptr_t>(A) & 127) == 0,
+                    "gmd_gemm_nt: a pre-split A operand (GMD_F32SA) needs lda and strideA multiples of 32 elements and a 128-byte aligned base");
     GMD_REQUIRE(bias == nullptr || gmd_aligned16(bias), "gmd_gemm_nt: bias must be 16-byte aligned (it is read with float4 loads)");
     GMD_REQUIRE(rowbias == nullptr || rows_per_group > 0, "gmd_gemm_nt: rows_per_group must be positive");
     GMD_REQUIRE(residual == nullptr || (ldr >= N && gmd_aligned16(residual)), "gmd_gemm_nt: bad residual");
@@ -2693,3 +2724,5 @@ int gmd_conv3x3_groupnorm(const void* X, const void* Wt, void* Yraw, void* Ynorm
 }
 
 }  // extern "C"
+
+GMD_WG_TRACE_SETTER(gemm)

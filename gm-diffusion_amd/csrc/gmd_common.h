@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/gmd_hip.h"
+#include "wg_trace.h"  // diagnostic build only; expands to nothing in the product
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;  // one MFMA A/B fragment (4 VGPRs)

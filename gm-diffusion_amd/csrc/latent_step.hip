@@ -18,6 +18,7 @@ __global__ __launch_bounds__(kThreads) void latent_step_kernel(
     int do_cfg, float gs, const float* __restrict__ ratio, float gr, int mode, float sample_coeff,
     float alpha_delta, float denom, float sqrt_a, float sqrt_1ma, float* __restrict__ eps_out,
     float* __restrict__ x_prev, float* __restrict__ x0) {
+    GMD_WG_TRACE_SCOPE(WGK_LATENT_STEP);
     const int64_t n = (int64_t)B * chw;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float eps;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(kThreads) void dpm_step_kernel(
     const float* __restrict__ eps_in, const float* __restrict__ x, const float* __restrict__ m1, int B, int64_t chw, int do_cfg,
     float gs, const float* __restrict__ ratio, float gr, int order, float sigma_s0, float alpha_s0, float c_x, float c_m, float c_h,
     float inv_r0, float sqrt_a, float sqrt_1ma, float* __restrict__ m0_out, float* __restrict__ x_prev, float* __restrict__ x0) {
+    GMD_WG_TRACE_SCOPE(WGK_LATENT_STEP);
     const int64_t n = (int64_t)B * chw;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float eps;
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(kThreads) void ddpm_step_kernel(
     float gs, const float* __restrict__ ratio, float gr, float sched_sqrt_a, float sched_sqrt_1ma, int clip, float clip_range,
     float x0_coeff, float xt_coeff, float noise_scale, float sqrt_a, float sqrt_1ma, float* __restrict__ x_prev,
     float* __restrict__ x0) {
+    GMD_WG_TRACE_SCOPE(WGK_LATENT_STEP);
     const int64_t n = (int64_t)B * chw;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float eps;
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(kThreads) void ddpm_step_kernel(
 // one block per sample: unbiased std over chw of text eps and of the guided eps
 __global__ __launch_bounds__(kThreads) void cfg_std_ratio_kernel(const float* __restrict__ eps_in, int B, int64_t chw,
                                                                  float gs, float* __restrict__ ratio) {
+    GMD_WG_TRACE_SCOPE(WGK_CFG_RATIO);
     const int b = blockIdx.x;
     const int64_t n = (int64_t)B * chw;
     const float* u = eps_in + (int64_t)b * chw;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(kThreads) void cfg_std_ratio_kernel(const float* __
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pack_kernel(const float* __restrict__ s0, int C0, const float* __restrict__ s1,
                                                         int C1, int B, int64_t HW, int dup, T* __restrict__ out, int CP) {
+    GMD_WG_TRACE_SCOPE(WGK_PACK);
     // one thread per (pixel, 8-channel group) of the padded output
     const int groups = CP / 8;
     const int64_t total = (int64_t)B * HW * groups;
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(kThreads) void unpack_kernel(const T* __restrict__ in, int64_t ld, int B, int C, int64_t HW,
                                                           float* __restrict__ out) {
+    GMD_WG_TRACE_SCOPE(WGK_UNPACK);
     const int64_t total = (int64_t)B * C * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i % HW;
@@ -289,3 +295,5 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
 }
 
 }  // extern "C"
+
+GMD_WG_TRACE_SETTER(latent_step)

@@ -17,6 +17,7 @@ constexpr int kThreads = 256;
 template <typename T>
 __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const T* __restrict__ X, int64_t HW, int C, int G,
                                                               int nsplit, float* __restrict__ ws) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_PARTIAL);
     constexpr int V = Elem<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [PY][C] sums, [PY][C] sumsq
     const int b = blockIdx.y, split = blockIdx.x;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const T* __restric
 __global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __restrict__ ws, int nsplit, int64_t HW, int C,
                                                                int G, float eps, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ ss) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_FINALIZE);
     __shared__ float s_mean[64], s_rstd[64];
     const int b = blockIdx.x, cpg = C / G;
     for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(kThreads) void gn_finalize_kernel(const float* __re
 template <typename T>
 __global__ __launch_bounds__(kThreads) void gn_apply_kernel(const T* __restrict__ X, T* __restrict__ Y, int B, int64_t HW, int C,
                                                             const float* __restrict__ ss, int silu) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_APPLY);
     constexpr int V = Elem<T>::kVec;
     const int CV = C / V;
     const int64_t total = (int64_t)B * HW * CV;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
                                                                int nsplit, float eps, const float* __restrict__ ws,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int silu) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_APPLY_WS);
     constexpr int V = Elem<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) float ss[];  // [C][2] = {scale, shift}
     __shared__ float s_mean[64], s_rstd[64];
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restri
                                                                const float* __restrict__ sb, int bucket,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int silu) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_APPLY_CS);
     constexpr int V = Elem<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) float ss[];  // [C][2] = {scale, shift}
     __shared__ float s_mean[64], s_rstd[64];
@@ -305,6 +310,7 @@ template <typename T, int VB>  // VB = bytes per access (4, 8 or 16): the widest
 __global__ __launch_bounds__(kThreads) void gn_fused_kernel(const T* __restrict__ X, T* __restrict__ Y, int HW, int C, int G,
                                                             float eps, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int silu) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_FUSED);
     constexpr int EP = VB / (int)sizeof(T);       // elements per access
     constexpr int NW = VB / 4;                    // 32-bit words per access
     typedef unsigned vec_t __attribute__((ext_vector_type(NW)));
@@ -443,6 +449,7 @@ template <typename T, int VB, int MAXIT>
 __global__ __launch_bounds__(kThreads) void gn_fused_reg_kernel(const T* __restrict__ X, T* __restrict__ Y, int HW, int C, int G,
                                                                 float eps, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int silu) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_FUSED_REG);
     constexpr int EP = VB / (int)sizeof(T);
     constexpr int NW = VB / 4;
     typedef unsigned vec_t __attribute__((ext_vector_type(NW)));
@@ -493,6 +500,7 @@ template <typename T, int MAXIT>
 __global__ __launch_bounds__(kThreads) void gn_slab_kernel(const SlabSource sp, T* __restrict__ Yraw, T* __restrict__ Y, int HW, int C,
                                                            int G, float eps, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int silu) {
+    GMD_WG_TRACE_SCOPE(WGK_GN_SLAB);
     constexpr int EP = 16 / (int)sizeof(T);  // elements per item: 8 (16-bit) or 4 (float32)
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y;
@@ -603,6 +611,7 @@ template <typename T, int MAXCH, int ROWS, bool SPLIT_OUT = false>
 __global__ __launch_bounds__(kThreads) void layernorm_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps) {
+    GMD_WG_TRACE_SCOPE(WGK_LN);
     // one wave per ROWS consecutive rows, each row held in registers (exact two-pass variance); the loads of all ROWS rows
     // are issued before the first reduction, so a wave keeps ROWS x MAXCH 16-byte loads in flight instead of MAXCH
     constexpr int V = Elem<T>::kVec;
@@ -677,6 +686,7 @@ template <typename T, int LPR, int CPL>
 __global__ __launch_bounds__(kThreads) void layernorm_packed_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t rows, int C,
                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                     float eps) {
+    GMD_WG_TRACE_SCOPE(WGK_LN_PACKED);
     constexpr int V = Elem<T>::kVec, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane % LPR;
     const int64_t row = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
@@ -726,6 +736,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_packed_kernel(const T* __r
 template <typename T>
 __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, T* __restrict__ P,
                                                                 int64_t ldp, int cols_all, float scale, int causal_nq) {
+    GMD_WG_TRACE_SCOPE(WGK_OTHER);
     __shared__ float red[kThreads / 64];
     const int64_t row = blockIdx.x;
     // causal rows attend columns 0 .. (row % Nq) only; the rest of the row is written as zeros
@@ -1025,3 +1036,5 @@ int gmd_softmax_rows(const float* S, int64_t lds_, void* P, int out_dtype, int64
 }
 
 }  // extern "C"
+
+GMD_WG_TRACE_SETTER(norm)

@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMD_LIB_OVERRIDE") or os.path.join(_HERE, "libgmd_hip.so")  # override: kernel-debug builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 GMD_F32, GMD_BF16, GMD_F16, GMD_F32S, GMD_F32SW, GMD_F32SA = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -42,6 +42,7 @@ SIGNATURES = {
     "gmd_pack_unet_input": [P, I, P, I, I, L, I, P, I, I, P],
     "gmd_unpack_nchw": [P, I, L, I, I, L, P, P],
     "gmd_gemm_plan_override": [I, I, I, I],
+    "gmd_gemm_plan_family": [I],
     "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, I, P, L, P],
     "gmd_gemm_colstats_plan": [I, I, I, I, I, L, I],
     "gmd_gemm_plan_info": [I, I, I, I, I, L, I, P],

@@ -61,23 +61,21 @@ def _pad_to(n, m):
 
 
 def _in_own_f32_mode(fn):
-    """Run a module's compute method under the float32 contraction mode its weights were laid out for.  The mode
-    (``hip_ops.F32_MODE``) is a process-wide switch that ``hip_ops`` reads at every call, while a module's weights are pre-split /
-    power-of-two scaled / channel-padded for ONE mode when they are placed on the device: a model prepared under "split" and run
-    after ``set_f32_mode("exact")`` (bench.py holds both kinds alive) would otherwise run the split kernels' weights through the
-    exact kernels or the other way round.  16-bit modules do not depend on the mode."""
+    """Run a module's compute method under the float32 contraction mode its weights were laid out for.  ``hip_ops`` reads the mode at
+    every call, while a module's weights are pre-split / power-of-two scaled / channel-padded for ONE mode when they are placed on
+    the device: a model prepared under "split" and run after ``set_f32_mode("exact")`` (bench.py holds both kinds alive) would
+    otherwise run the split kernels' weights through the exact kernels or the other way round.  The override is scoped to the calling
+    THREAD (``hip_ops.f32_mode_scope``): two host threads driving a "split" and an "exact" module at the same time keep their own
+    modes.  16-bit modules do not depend on the mode."""
     import functools
 
     @functools.wraps(fn)
     def run(self, *args, **kwargs):
         self._ensure()
-        if self._dtype != torch.float32 or self._f32_mode == ops.F32_MODE:
+        if self._dtype != torch.float32 or self._f32_mode == ops.f32_mode():
             return fn(self, *args, **kwargs)
-        prev = ops.set_f32_mode(self._f32_mode)
-        try:
+        with ops.f32_mode_scope(self._f32_mode):
             return fn(self, *args, **kwargs)
-        finally:
-            ops.set_f32_mode(prev)
 
     return run
 
@@ -149,7 +147,7 @@ class _HipModule(ConfigMixin):
             raise HipExtensionError(f"{type(self).__name__} runs on hand-written HIP kernels only; call .to('cuda') "
                                     "(there is no CPU fallback in the MI355X build)")
         ops.dtype_code(self._dtype)
-        self._f32_mode = ops.F32_MODE  # _prepare and every later forward of this module use THIS mode (_in_own_f32_mode)
+        self._f32_mode = ops.f32_mode()  # _prepare and every later forward of this module use THIS mode (_in_own_f32_mode)
         self._w = self._prepare()
 
     # -- layout helpers --------------------------------------------------------------------------
@@ -165,7 +163,7 @@ class _HipModule(ConfigMixin):
 
     def _split_mode(self):
         """float32 module laid out for the matrix-core ("split") kernels: from the record taken when the weights were prepared."""
-        return self._dtype == torch.float32 and (self._f32_mode or ops.F32_MODE) == "split"
+        return self._dtype == torch.float32 and (self._f32_mode or ops.f32_mode()) == "split"
 
     def _wt(self, t):
         """A weight that is the W operand of gemm_nt / conv3x3.  float32 on the matrix cores: scaled by a power of two and
@@ -802,8 +800,10 @@ class UNet2DConditionModel(_HipModule):
         return out
 
     @_in_own_f32_mode
-    def graphed_forward(self, B, H, W, ehs, cfg_shared=False):
+    def graphed_forward(self, B, H, W, ehs, cfg_shared=False, co_run=False):
         """Capture ``forward_packed`` for this (batch, latent size) into a HIP graph (one per shape, cached).
+        ``co_run``: the replays share the chip with another stream's forward (the dual-UNet pipeline's two streams): the launches are
+        captured under the co-running plan family (``hip_ops.plan_family``, gmd_gemm_plan_family) -- a separate cache entry.
         Returns an object with ``.x`` (static packed-input buffer: fill it with ``pack_input(..., out=g.x)``) and
         ``.replay()`` -> float32 eps [B, out_channels, H, W] (static output buffer).  The timestep is read from the
         device scalar written by ``set_timestep``; the text conditioning from the in-place K / V^T buffers written by
@@ -812,7 +812,7 @@ class UNet2DConditionModel(_HipModule):
         self.update_context(ehs)
         if self.config.addition_embed_type is not None and B not in self._aug:
             raise HipExtensionError("set_added_cond(added_cond_kwargs, batch) must precede graphed_forward for this UNet")
-        key = (B, H, W, tuple(ehs.shape), bool(cfg_shared))
+        key = (B, H, W, tuple(ehs.shape), bool(cfg_shared), bool(co_run))
         g = self._graphs.get(key)
         if g is not None:
             return g
@@ -826,7 +826,7 @@ class UNet2DConditionModel(_HipModule):
         cur = torch.cuda.current_stream(self._device)
         side = torch.cuda.Stream(device=self._device)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):  # warm-up on a side stream: one-time attribute calls, workspaces, allocator pools
+        with torch.cuda.stream(side), ops.plan_family(co_run):  # warm-up on a side stream: one-time attribute calls, workspaces, allocator pools
             for _ in range(2):
                 self.forward_packed(g.x, B, H, W, ehs, cfg_shared=cfg_shared)
         cur.wait_stream(side)
@@ -835,7 +835,7 @@ class UNet2DConditionModel(_HipModule):
         g.ws = ops.new_workspace(self._device)  # this graph's own split-K scratch (see hip_ops.workspace_scope)
         self._capturing = True
         try:
-            with ops.capture_in_flight(), ops.workspace_scope(g.ws), torch.cuda.graph(g.graph):
+            with ops.capture_in_flight(), ops.workspace_scope(g.ws), ops.plan_family(co_run), torch.cuda.graph(g.graph):
                 g.out = self.forward_packed(g.x, B, H, W, ehs, cfg_shared=cfg_shared)
         finally:
             self._capturing = False

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 import time
 
 import torch
@@ -47,23 +48,73 @@ HALF_DTYPES = (torch.bfloat16, torch.float16)
 #            (~2^-22 relative per term) at matrix-core speed -- the reference's own float32 numerics
 #            (scripts/inference/experiments/formal_improved.py:199), the path that meets the 1e-3 latent-RMS gate;
 #   "exact": the float32 FMA kernels on the vector units (bit-for-bit an fp32 FMA chain, ~12x slower end to end).
-F32_MODE = os.environ.get("GMD_F32_MODE", "split")
-if F32_MODE not in ("split", "exact"):
-    raise HipExtensionError(f"GMD_F32_MODE={F32_MODE!r}: expected 'split' or 'exact'")
+_F32_DEFAULT = os.environ.get("GMD_F32_MODE", "split")  # the process default; read through f32_mode() / hip_ops.F32_MODE
+if _F32_DEFAULT not in ("split", "exact"):
+    raise HipExtensionError(f"GMD_F32_MODE={_F32_DEFAULT!r}: expected 'split' or 'exact'")
+# Per-thread state: a module call that runs under its own float32 mode (components: _in_own_f32_mode), a graph capture's workspace
+# (workspace_scope) and the plan family of a co-running forward (plan_family) are scoped to the CALLING THREAD -- two host threads
+# driving a "split" and an "exact" module at the same time never see each other's mode.
+_tls = threading.local()
+
+
+def f32_mode():
+    """The float32 contraction mode in effect for the calling thread: its scoped override (f32_mode_scope) or the process default."""
+    return getattr(_tls, "f32_mode", None) or _F32_DEFAULT
+
+
+def __getattr__(name):  # hip_ops.F32_MODE stays readable (tests, tools): the calling thread's effective mode
+    if name == "F32_MODE":
+        return f32_mode()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def set_f32_mode(mode):
-    """Switch float32 contractions between "split" (matrix cores, three float16 products) and "exact" (vector FMA).
-    Models prepare their weights for the mode that is active when they are placed on the device."""
-    global F32_MODE
+    """Switch the PROCESS DEFAULT of float32 contractions between "split" (matrix cores, three float16 products) and "exact" (vector
+    FMA); returns the previous default.  Models prepare their weights for the mode in effect when they are placed on the device and
+    keep running under it (f32_mode_scope), whatever the default becomes later."""
+    global _F32_DEFAULT
     if mode not in ("split", "exact"):
         raise HipExtensionError("f32 mode must be 'split' or 'exact'")
-    prev, F32_MODE = F32_MODE, mode
+    prev, _F32_DEFAULT = _F32_DEFAULT, mode
     return prev
 
 
+class f32_mode_scope:
+    """Run the ``with`` block under ``mode`` on the calling thread only (other threads keep theirs)."""
+
+    def __init__(self, mode):
+        if mode not in ("split", "exact"):
+            raise HipExtensionError("f32 mode must be 'split' or 'exact'")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "f32_mode", None)
+        _tls.f32_mode = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _tls.f32_mode = self.prev
+        return False
+
+
 def f32_split():
-    return F32_MODE == "split"
+    return f32_mode() == "split"
+
+
+class plan_family:
+    """Select the launch-plan family of the calling thread's 16-bit contractions for the ``with`` block (gmd_gemm_plan_family):
+    1 = co-running (the dual-UNet pipeline's two overlapped forwards), 0 = a launch that has the chip to itself (the default)."""
+
+    def __init__(self, family):
+        self.family = 1 if family else 0
+
+    def __enter__(self):
+        self.prev = lib().gmd_gemm_plan_family(self.family)
+        return self
+
+    def __exit__(self, *exc):
+        lib().gmd_gemm_plan_family(self.prev)
+        return False
 
 
 def check_split_range(what, *tensors, module=None):
@@ -73,7 +124,7 @@ def check_split_range(what, *tensors, module=None):
     consumers -- both pipelines on their final latents, ``hdr.decode_to_hdr`` on the decoded images -- call this once per run
     on their OUTPUTS (a NaN reaches them through every following layer).  One reduction and one host synchronisation; only for
     float32 tensors produced under "split".  Raises instead of returning poisoned images."""
-    mode = getattr(module, "_f32_mode", None) or F32_MODE
+    mode = getattr(module, "_f32_mode", None) or f32_mode()
     if mode != "split":
         return
     for t in tensors:
@@ -135,7 +186,7 @@ def _mark_asplit(t):
 
 def want_split_out(dtype, row_len):
     """A producer may store its float32 output pre-split: split mode on the matrix cores, rows of whole 32-element chunks."""
-    return USE_F32SA and dtype == torch.float32 and F32_MODE == "split" and row_len % 32 == 0
+    return USE_F32SA and dtype == torch.float32 and f32_mode() == "split" and row_len % 32 == 0
 
 
 def split_activation(x):
@@ -164,7 +215,7 @@ def _contract_code(a, w, K, a_split=False):
         return GMD_F32SA
     if getattr(w, "_split", False):
         return GMD_F32SW
-    return GMD_F32S if (F32_MODE == "split" and K % 32 == 0) else GMD_F32
+    return GMD_F32S if (f32_mode() == "split" and K % 32 == 0) else GMD_F32
 
 
 def is_half(dt):
@@ -195,11 +246,8 @@ _WS = {}
 WORKSPACE_BYTES = 96 << 20
 
 
-_WS_OVERRIDE = None
-
-
 class workspace_scope:
-    """Route every split-K launch issued inside the ``with`` block to ``ws`` (a float32 device tensor of
+    """Route every split-K launch the calling thread issues inside the ``with`` block to ``ws`` (a float32 device tensor of
     WORKSPACE_BYTES).  HIP-graph capture uses it: all captures run on torch's one capture stream, so the per-stream
     table below would hand the SAME scratch to two graphs that are later replayed concurrently on different streams."""
 
@@ -207,13 +255,12 @@ class workspace_scope:
         self.ws = ws
 
     def __enter__(self):
-        global _WS_OVERRIDE
-        self.prev, _WS_OVERRIDE = _WS_OVERRIDE, self.ws
+        self.prev = getattr(_tls, "ws_override", None)
+        _tls.ws_override = self.ws
         return self.ws
 
     def __exit__(self, *exc):
-        global _WS_OVERRIDE
-        _WS_OVERRIDE = self.prev
+        _tls.ws_override = self.prev
         return False
 
 
@@ -224,8 +271,9 @@ def new_workspace(device):
 def _workspace(device):
     """Persistent float32 scratch, one per (device, stream) so that concurrent streams never share it; it lets
     under-filled GEMM/conv launches split K."""
-    if _WS_OVERRIDE is not None:
-        return _WS_OVERRIDE
+    ov = getattr(_tls, "ws_override", None)
+    if ov is not None:
+        return ov
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
@@ -754,6 +802,7 @@ def side_stream(device):
 
 _SPIN_TICKS = 1_000_000  # ~0.4 ms of torch.cuda._sleep at the MI355X shader clock
 _CAPTURES_IN_FLIGHT = 0  # HIP-graph captures this package has open (components: graphed_forward) -- on ANY stream or thread
+_CAPTURES_LOCK = threading.Lock()  # the count is deliberately process-wide (a capture on another thread matters too): guarded
 _PROBE_WARNED = False
 
 
@@ -763,11 +812,13 @@ class capture_in_flight:
 
     def __enter__(self):
         global _CAPTURES_IN_FLIGHT
-        _CAPTURES_IN_FLIGHT += 1
+        with _CAPTURES_LOCK:
+            _CAPTURES_IN_FLIGHT += 1
 
     def __exit__(self, *exc):
         global _CAPTURES_IN_FLIGHT
-        _CAPTURES_IN_FLIGHT -= 1
+        with _CAPTURES_LOCK:
+            _CAPTURES_IN_FLIGHT -= 1
         return False
 
 
@@ -793,10 +844,16 @@ def _stream_beside_current(device, candidates=8):
     candidate is used and ONE RuntimeWarning says so."""
     skip = os.environ.get("GMD_SIDE_STREAM_SKIP")
     if skip is not None:
-        junk = [torch.cuda.Stream(device=device) for _ in range(max(0, int(skip)))]
-        st = torch.cuda.Stream(device=device)
-        del junk
-        return st
+        try:
+            n = max(0, int(skip))
+        except ValueError:  # a malformed escape hatch is no reason to fail either: say so once and probe as usual
+            _probe_note(f"GMD_SIDE_STREAM_SKIP={skip!r} is not an integer; ignored")
+            n = None
+        if n is not None:
+            junk = [torch.cuda.Stream(device=device) for _ in range(n)]
+            st = torch.cuda.Stream(device=device)
+            del junk
+            return st
     first = torch.cuda.Stream(device=device)
     try:
         with torch.cuda.device(device):
@@ -1045,7 +1102,7 @@ def gemm_raw(a_ptr, w_ptr, c_ptr, dtype, out_dtype, M, N, K, lda, ldw, ldc, batc
     """Pointer-level gmd_gemm_nt for strided sub-blocks (per-head attention products of the parity path).
     a_ptr/w_ptr/c_ptr are integer device addresses; the caller keeps the owning tensors alive."""
     _dev(bias)
-    code = GMD_F32S if (dtype == torch.float32 and F32_MODE == "split" and K % 32 == 0 and not exact) else dtype_code(dtype)
+    code = GMD_F32S if (dtype == torch.float32 and f32_mode() == "split" and K % 32 == 0 and not exact) else dtype_code(dtype)
     check(lib().gmd_gemm_nt(a_ptr, w_ptr, c_ptr, code, dtype_code(out_dtype), M, N, K, lda, ldw, ldc, batch,
                             sA, sW, sC, _ptr(_f32(bias, "bias")), None, 0, 0, None, 0, 0, float(alpha), act, None, 0, None, 0, _stream()),
           "gmd_gemm_nt")

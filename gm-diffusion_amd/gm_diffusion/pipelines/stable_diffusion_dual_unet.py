@@ -180,9 +180,13 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
             g_sdr = g_gm = None
             shared = self._cfg_shared(self.unet, do_cfg)
             nb_sdr = (2 if do_cfg else 1) * latents.shape[0]
+            # two forwards in flight side by side: their contractions take the co-running plan family (fewest L2 -> LDS bytes per
+            # product; -2.2 % per batch against the launch-by-launch plans, +8.6 % if the streams were serialised:
+            # profiles/r05_ab_plan_default.txt), a single-stream run keeps the plans that are fastest alone
+            co_run = gm_stream is not sdr_stream
             if self._graphs_ok():
-                g_sdr = self.unet.graphed_forward(nb_sdr, h, w, ctx, cfg_shared=shared)
-                g_gm = self.gm_unet.graphed_forward(latents.shape[0], h, w, gm_ctx)
+                g_sdr = self.unet.graphed_forward(nb_sdr, h, w, ctx, cfg_shared=shared, co_run=co_run)
+                g_gm = self.gm_unet.graphed_forward(latents.shape[0], h, w, gm_ctx, co_run=co_run)
             pre = self._predraw_step_noise([self.scheduler, self.gm_scheduler], ts_host, latents.shape, generator, latents.device)
             gm_stream.wait_stream(sdr_stream)
             if gm_stream is not sdr_stream:
@@ -197,7 +201,11 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                 if fused:
                     x = self.unet.pack_input(latents, dup=2 if (do_cfg and not shared) else 1, out=g_sdr.x if g_sdr else None)
                     self.unet.set_timestep_from(ts_dev, i)
-                    sdr_noise_pred = g_sdr.replay() if g_sdr else self.unet.forward_packed(x, nb_sdr, h, w, ctx, cfg_shared=shared)
+                    if g_sdr:
+                        sdr_noise_pred = g_sdr.replay()
+                    else:
+                        with ops.plan_family(co_run):
+                            sdr_noise_pred = self.unet.forward_packed(x, nb_sdr, h, w, ctx, cfg_shared=shared)
                     pre_step = latents
                     latents, x0_latent = self.scheduler.fused_step(sdr_noise_pred, ts_host[i], pre_step, do_cfg, self.guidance_scale,
                                                                    self.guidance_rescale if do_cfg else 0.0, want_x0=True,
@@ -208,7 +216,11 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
                         x0_latent.record_stream(gm_stream)
                         gx = self.gm_unet.pack_input((x0_latent, gm_latents), dup=1, out=g_gm.x if g_gm else None)
                         self.gm_unet.set_timestep_from(ts_dev, i)
-                        gm_noise_pred = g_gm.replay() if g_gm else self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
+                        if g_gm:
+                            gm_noise_pred = g_gm.replay()
+                        else:
+                            with ops.plan_family(co_run):
+                                gm_noise_pred = self.gm_unet.forward_packed(gx, gx.shape[0], h, w, gm_ctx)
                         gm_latents = self.gm_scheduler.step(gm_noise_pred, ts_host[i], gm_latents,
                                                             **self._fused_step_kwargs(extra_step_kwargs),
                                                             **({"noise": pre[1][i]} if pre else {}), return_dict=False)[0]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GMD_ABI_VERSION 10
+#define GMD_ABI_VERSION 11
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -53,7 +53,9 @@ extern "C" {
  * gmd_gemm_nt (GEGLU and plain row epilogues of the split types) and as `dtype` of gmd_layernorm / gmd_groupnorm_colstats /
  * gmd_groupnorm_split / gmd_attention (there: Q, K, V^T plain as for GMD_F32S): float32 tensors in, the OUTPUT stored pre-split (rows
  * must be multiples of 32 elements, the buffer contiguous).  Such a tensor is
- * only ever an A (or W) operand of a contraction: nothing else reads it. */
+ * only ever an A (or W) operand of a contraction: nothing else reads it.  A pre-split operand (A under GMD_F32SA, W under GMD_F32SW /
+ * GMD_F32SA) must start on a 128-byte boundary and have its leading dimension and batch stride in whole chunks (multiples of 32
+ * elements): a column-offset view or a ragged leading dimension would be read as the wrong halves -- refused with GMD_ERR_INVALID. */
 #define GMD_F32SA 5
 
 /* epilogue activation for gmd_gemm_nt */
@@ -194,6 +196,15 @@ int gmd_unpack_nchw(const void* in, int in_dtype, int64_t ld, int B, int C, int6
  * gate.  A forced plan whose kernel lacks the epilogue a launch asks for (fused GEGLU, column statistics) is refused at the
  * launch, never run. */
 int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit);
+
+/* Plan family of the CALLING THREAD's later 16-bit gmd_gemm_nt / gmd_conv3x3 / gmd_gemm_qkv_vt launches (and of the plan queries
+ * gmd_gemm_colstats_plan / gmd_gemm_plan_info / gmd_gemm_qkv_vt_ok, which must agree with them): 0 (the default) = the plan that is
+ * fastest when the launch has the chip to itself; 1 = the co-running family (256-row tiles, filled up with K slices: fewest L2 -> LDS
+ * bytes per product) for launches that share the chip with a second stream's kernels -- what the dual-UNet pipeline selects around
+ * its two overlapped forwards (stable_diffusion_dual_unet.py:1040-1093: the two UNet calls of one loop iteration).  Results of the
+ * two families agree to float32 summation order (K slices).  Returns the previous family; any other argument only queries.  Thread-
+ * local, so concurrent host threads do not see each other's choice.  GMD_PP=b / GMD_PP=1 in the environment pin 1 / 0 process-wide. */
+int gmd_gemm_plan_family(int family);
 
 /* C[b] = act(alpha * A[b] @ W[b]^T + bias + rowbias + residual).
  * A: [M,K] ld lda; W: [N,K] ld ldw (both K-contiguous); C: [M,N] ld ldc, out_dtype F32 or `dtype`.

@@ -1,5 +1,6 @@
-"""CPU, world_size 2 over gloo: prompt-batch sharding (broadcast from rank 0, contiguous slices, ragged gather)
-and shard-independence of the results -- the union of the per-rank outputs equals the single-process run."""
+"""CPU, world_size 2 and 8 over gloo: prompt-batch sharding (broadcast from rank 0, contiguous slices, ragged gather)
+and shard-independence of the results -- the union of the per-rank outputs equals the single-process run.  World 8 with a global
+batch of 64 is BASELINE.json configs[2]'s split (8 prompts per rank); 61 is its ragged case (5 ranks of 8, 3 of 7)."""
 import os
 import socket
 import sys
@@ -54,6 +55,49 @@ def _worker(rank, world, port, total, out_dir):
         assert full is None
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _single_process_pipe():
+    from gm_diffusion.components import PNDMScheduler
+    from gm_diffusion.pipelines import StableDiffusionDualUNetPipeline
+    from oracle import fixtures
+
+    class FakeVae:
+        class config:
+            block_out_channels = [1, 2, 3, 4]
+            scaling_factor = 0.18215
+
+    pipe = StableDiffusionDualUNetPipeline(
+        vae=FakeVae(), text_encoder=None, tokenizer=None, unet=fixtures.build_unet("tiny", 4), gm_unet=fixtures.build_unet("tiny", 8),
+        scheduler=PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1),
+        safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    pipe.set_progress_bar_config(disable=True)
+    return pipe
+
+
+@pytest.mark.parametrize("total", [64, 61])  # BASELINE configs[2]: global batch 64 over 8 ranks; 61 = ragged (8,8,8,8,8,7,7,7)
+def test_eight_rank_sharding_is_bitwise_the_single_process_run(tmp_path, total):
+    """World 8 through the real collectives (broadcast of [negative; positive] hidden states and of the initial latents from rank 0,
+    ragged gather on rank 0): every sample equals, BIT FOR BIT, the same pipeline run in ONE process on the same contiguous slice --
+    the collectives and the slicing change nothing -- and agrees to 1e-5 with the single-process run of the whole batch at once
+    (per-sample results do not depend on the batch they ran in; only the host GEMM blocking differs with the batch size)."""
+    from gm_diffusion.distributed import shard_range
+    from oracle import fixtures
+
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, total, str(tmp_path)), nprocs=8, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.shape[0] == total
+    torch.set_num_threads(2)  # the workers' setting: the same host kernels, blocking and summation order
+    pos, neg, lat = fixtures.make_inputs(total, 8, 8, cross_dim=64)
+    pipe = _single_process_pipe()
+    kw = dict(height=64, width=64, num_inference_steps=3, output_type="latent")
+    for r in range(8):
+        lo, hi = shard_range(total, r, 8)
+        sdr, gm = pipe(prompt_embeds=pos[lo:hi].contiguous(), negative_prompt_embeds=neg[lo:hi].contiguous(), latents=lat[lo:hi].contiguous(), **kw)
+        assert np.array_equal(got[lo:hi], torch.cat([sdr, gm], 1).numpy()), f"rank {r}: rows {lo}..{hi} differ from the single-process slice"
+    sdr, gm = pipe(prompt_embeds=pos, negative_prompt_embeds=neg, latents=lat, **kw)
+    assert np.allclose(got, torch.cat([sdr, gm], 1).numpy(), atol=1e-5)
 
 
 @pytest.mark.parametrize("total", [4, 3])  # 3 = ragged split (2 + 1)
