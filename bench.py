@@ -274,6 +274,8 @@ def main():
     path_diff = None
     if not a.no_kernel_timing and rank == 0:
         pipe.overlap_streams = False  # one stream: an event pair then brackets exactly one kernel running alone
+        if hasattr(pipe, "co_run_plans"):
+            pipe.co_run_plans = not a.no_overlap  # ... and the SAME launch plans as the timed region (its co-running family)
         # An event pair brackets a kernel only while the GPU has a backlog: when the GPU waits for the host (~33 k eager launches +
         # 66 k event records per step, host time ~ GPU time), elapsed(e0, e1) also holds the wait for the next launch, and the
         # short, numerous gemm_nt launches read 30 % too long on a box with a slow host (round 3: 36.8 vs 28.3 us average).  So
@@ -300,6 +302,8 @@ def main():
         # inputs: their HDR images must be bit-identical -- a full-size guard against cross-stream races
         path_diff = float((out_eager["hdr"] - out["hdr"]).abs().max().item())
         pipe.overlap_streams = not a.no_overlap
+        if hasattr(pipe, "co_run_plans"):
+            pipe.co_run_plans = None
     if use_dist:
         dist.barrier()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -49,9 +49,10 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
         if (j < nvalid) {
             float x = v[j] * p.alpha;
             if (p.bias) x += p.bias[n + j];
-            if (rb) x += rb[n + j];
-            if (res) x += rv[j];
-            v[j] = apply_act(x, p.act);
+            float add = 0.f;  // (acc*alpha + bias) + (residual + rowbias): the association of epilogue_regs / epilogue_rows
+            if (res) add += rv[j];
+            if (rb) add += rb[n + j];
+            v[j] = apply_act(x + add, p.act);
         }
     }
     const int64_t coff = (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
@@ -365,6 +366,69 @@ __device__ __forceinline__ void epilogue_rows_slab(const GemmParams& p, const f3
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// In-kernel split-K reduction (round 5).  Grid z = K slice, and workgroups are dispatched in increasing linear id (x fastest, z
+// slowest), so every workgroup of the slices 0 .. ksplit-2 of ANY tile has been placed on a CU before the first workgroup of the
+// last slice is: the last slice -- the only one that waits -- can never hold a CU that a workgroup it waits for still needs, whatever
+// another stream's kernels occupy (the same argument the vendor library's stream-K fix-up rests on).  The spin is bounded all the same.
+//   slices 0 .. ksplit-2 ("producers"): every consumer wave stores its TM x TN accumulator fragments to the fragment area, lane-
+//     linear (one 1 KB store instruction per fragment: whole 128-byte lines by one instruction of one wave), with sc1 stores;
+//     s_waitcnt vmcnt(0); workgroup barrier; ONE lane adds 1 to the tile's arrival counter (agent scope); the workgroup ends.
+//   slice ksplit-1 ("finisher"): ONE lane polls the counter with sc1 loads until ksplit-1 producers have arrived; workgroup barrier;
+//     every wave reads the same fragments back with sc1 loads and forms (s_0 + s_1 + ... + s_{ksplit-2}) + own -- the order of
+//     splitk_reduce_kernel, so the result is bit-identical to the slab path -- then the counter is put back to 0 and the caller goes
+//     on to the fused epilogue of an unsplit launch.  (Hand-off protocol: MI355X_MICROARCH.md, "sc1 loads in place of the acquire",
+//     first row: sc1 stores of 16 bytes, one signalling lane per storing workgroup behind its barrier, sc1 poll, barrier, sc1 loads.)
+// Returns false in a producer (the kernel returns), true in the finisher.  NCONS consumer waves = waves 0 .. NCONS-1 of the workgroup;
+// the loader waves have ended by now (s_barrier counts the surviving waves only).
+template <int TM, int TN, int NCONS>
+__device__ __forceinline__ bool splitk_fixup(const GemmParams& p, f32x4 (&acc)[TM][TN], int ks, int wid, int lane) {
+    constexpr unsigned FR = TM * TN;  // fragments (16 bytes per lane) per wave
+    const unsigned tile = blockIdx.x, ntiles = gridDim.x;
+    const int last = p.ksplit - 1;
+    unsigned* cnt = p.fix_cnt + tile;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)p.fix_bytes, 0x00020000);
+    const unsigned wave_off = ((tile * NCONS + (unsigned)wid) * FR) * 1024u + (unsigned)lane * 16u;
+    const unsigned slice_bytes = ntiles * NCONS * FR * 1024u;
+    if (ks != last) {
+        const unsigned base = (unsigned)ks * slice_bytes + wave_off;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, base + (unsigned)(i * TN + j) * 1024u, 0, 16 /* sc1 */);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every storing wave has waited for its stores
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    if (threadIdx.x == 0) {
+        int spins = 0;  // bounded: a grid must drain whatever happens (2^21 polls of >= 0.3 us each; never reached in a healthy run)
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)last && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        f32x4 t[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            t[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wave_off + (unsigned)(i * TN + j) * 1024u, 0, 16 /* sc1 */));
+        for (int s = 1; s < last; ++s) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                t[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * slice_bytes + wave_off + (unsigned)(i * TN + j) * 1024u, 0, 16));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            acc[i][j] = t[j] + acc[i][j];
+            // one row of fragments in flight at a time (TN x 4 temporaries, not TM x TN x 4: spills): the sums of this row exist
+            // before any load of the next row is issued
+            asm volatile("" : "+v"(acc[i][j])::"memory");
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch
+    return true;
 }
 
 // GEGLU variant of epilogue_rows: h * gelu(g) is formed in registers exactly as in epilogue_regs (value / gate tiles of a
@@ -1201,30 +1265,35 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
 #endif
         if (!late) seg_barrier();
     }
-    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
-                         (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
-                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
-                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     __syncthreads();  // every wave (loaders included) is done with the K-loop stages: the strips below overwrite them
+    GemmParams q = p;
+    if (p.fixup) {  // in-kernel split-K reduction: the producer slices leave here, the last slice goes on as an unsplit launch
+        if (!splitk_fixup<TM, TN, NCONS>(p, acc, ks, wid, lane)) return;
+        q.ksplit = 1;
+    }
+    const bool rows_ok = !q.out_f32 && q.ksplit <= 1 && q.act != GMD_ACT_GEGLU && m0 + BM <= q.M && n0 + BN <= q.N && (q.ldc & 7) == 0 &&
+                         (q.sC & 7) == 0 && (q.residual == nullptr || ((q.ldr & 7) == 0 && (q.sR & 7) == 0)) &&
+                         (q.rowbias == nullptr || ((q.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0;
     if constexpr (TN % 2 == 0) {
-        if (p.act == GMD_ACT_GEGLU && !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
-            (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+        if (q.act == GMD_ACT_GEGLU && !q.out_f32 && q.ksplit <= 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.ldc & 7) == 0 && (q.sC & 7) == 0 &&
+            (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0) {
             constexpr int kStripG = 32 * (TN * 8 + 4);
-            epilogue_rows_geglu<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+            epilogue_rows_geglu<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
             return;
         }
     }
-    if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+    if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
         constexpr int kStripS = 32 * (TN * 16 + 4);
-        epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
         return;
     }
     if (rows_ok) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
         static_assert((size_t)NCONS * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
-        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+        epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
     } else {
-        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+        epilogue_regs<HT, TM, TN>(q, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
     }
 }
 #undef PP_STAMP
@@ -1451,32 +1520,37 @@ __global__ __launch_bounds__(512, 2) void gemm_lc_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, fb0[j])));
     }
-    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && p.act != GMD_ACT_GEGLU && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
-                         (p.sC & 7) == 0 && (p.residual == nullptr || ((p.ldr & 7) == 0 && (p.sR & 7) == 0)) &&
-                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
-                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     __syncthreads();  // every wave (loaders included) is done with the K-loop stages: the strips below overwrite them
+    GemmParams q = p;
+    if (p.fixup) {  // in-kernel split-K reduction: the producer slices leave here, the last slice goes on as an unsplit launch
+        if (!splitk_fixup<TM, TN, NCONS>(p, acc, ks, wid, lane)) return;
+        q.ksplit = 1;
+    }
+    const bool rows_ok = !q.out_f32 && q.ksplit <= 1 && q.act != GMD_ACT_GEGLU && m0 + BM <= q.M && n0 + BN <= q.N && (q.ldc & 7) == 0 &&
+                         (q.sC & 7) == 0 && (q.residual == nullptr || ((q.ldr & 7) == 0 && (q.sR & 7) == 0)) &&
+                         (q.rowbias == nullptr || ((q.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0;
     if constexpr (TM == 4 && TN % 2 == 0) {
-        if (p.act == GMD_ACT_GEGLU && !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
-            (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {
+        if (q.act == GMD_ACT_GEGLU && !q.out_f32 && q.ksplit <= 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.ldc & 7) == 0 && (q.sC & 7) == 0 &&
+            (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0) {
             constexpr int kStripG = 32 * (TN * 8 + 4);
-            epilogue_rows_geglu<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, z);
+            epilogue_rows_geglu<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, z);
             return;
         }
     }
     if constexpr (TM == 4) {
-        if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+        if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
             constexpr int kStripS = 32 * (TN * 16 + 4);
-            epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, ks);
+            epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, ks);
             return;
         }
     }
     if (rows_ok) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
         static_assert((size_t)NCONS * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
-        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, z);
+        epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, z);
     } else {
-        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), frow, fq, z, ks);
+        epilogue_regs<HT, TM, TN>(q, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), frow, fq, z, ks);
     }
 }
 
@@ -1721,21 +1795,26 @@ __global__ __launch_bounds__(768, 3) void conv_patch_kernel(const GemmParams p) 
         if (!late) seg_barrier();
     }
     const int z = 0;
-    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
-                         (p.residual == nullptr || (p.ldr & 7) == 0) &&
-                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
-                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     __syncthreads();
-    if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+    GemmParams q = p;
+    if (p.fixup) {  // in-kernel split-K reduction: the producer slices leave here, the last slice goes on as an unsplit launch
+        if (!splitk_fixup<TM, TN, NCONS>(p, acc, ks, wid, lane)) return;
+        q.ksplit = 1;
+    }
+    const bool rows_ok = !q.out_f32 && q.ksplit <= 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.ldc & 7) == 0 &&
+                         (q.residual == nullptr || (q.ldr & 7) == 0) &&
+                         (q.rowbias == nullptr || ((q.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0;
+    if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
         constexpr int kStripS = 32 * (TN * 16 + 4);
-        epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
         return;
     }
     if (rows_ok) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
-        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+        epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
     } else {
-        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+        epilogue_regs<HT, TM, TN>(q, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
     }
 }
 
@@ -1944,21 +2023,26 @@ __global__ __launch_bounds__(768, 3) void conv_patch_cont_kernel(const GemmParam
         }
     }
     const int z = 0;
-    const bool rows_ok = !p.out_f32 && p.ksplit <= 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 7) == 0 &&
-                         (p.residual == nullptr || (p.ldr & 7) == 0) &&
-                         (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0)) &&
-                         (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
     __syncthreads();
-    if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0) {
+    GemmParams q = p;
+    if (p.fixup) {  // in-kernel split-K reduction: the producer slices leave here, the last slice goes on as an unsplit launch
+        if (!splitk_fixup<TM, TN, NCONS>(p, acc, ks, wid, lane)) return;
+        q.ksplit = 1;
+    }
+    const bool rows_ok = !q.out_f32 && q.ksplit <= 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.ldc & 7) == 0 &&
+                         (q.residual == nullptr || (q.ldr & 7) == 0) &&
+                         (q.rowbias == nullptr || ((q.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.rowbias) & 15) == 0)) &&
+                         (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0;
+    if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
         constexpr int kStripS = 32 * (TN * 16 + 4);
-        epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
         return;
     }
     if (rows_ok) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
-        epilogue_rows<HT, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+        epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
     } else {
-        epilogue_regs<HT, TM, TN>(p, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
+        epilogue_regs<HT, TM, TN>(q, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
     }
 }
 
@@ -2093,6 +2177,9 @@ int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e
 // it with gmd_gemm_plan_family(); GMD_PP=b / GMD_PP=1 pin family 1 / 0 for the whole process (A/B runs), read once at load time.
 const int g_family_pin = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b') ? 1 : ((e && e[0] == '1') ? 0 : -1); }();
 thread_local int t_plan_family = 0;
+const int g_family1_ks_cap = [] { const char* e = getenv("GMD_KS_CAP"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();  // A/B only
+// In-kernel split-K reduction up to this many K slices (0 = off: slabs + reduction launch everywhere).  GMD_SPLITK_FIXUP=<n>, read once.
+int g_fixup_max = [] { const char* e = getenv("GMD_SPLITK_FIXUP"); return e ? atoi(e) : 4; }();  // gmd_splitk_fixup_max() changes it in-process
 inline bool big_tiles() { return (g_family_pin >= 0 ? g_family_pin : t_plan_family) == 1; }
 
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
@@ -2167,7 +2254,7 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
             } else if (bn && M >= 256) {
                 const int64_t t = mt256 * (N / bn);
                 int ks = t >= 256 ? 1 : (int)((256 + t / 2) / t);
-                if (ks > 8) ks = 8;
+                if (ks > g_family1_ks_cap) ks = g_family1_ks_cap;
                 while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
                 pl = Plan{256, bn, 283, ks};
             }
@@ -2297,11 +2384,21 @@ hipError_t launch_pp(const GemmParams& p, int gz, hipStream_t s) {
 // heuristic actually picks; the register-staged and deeper-ring tuning variants exist for bfloat16 only (plan overrides).
 // Column statistics (GemmParams::colstats) come out of the row epilogue of the default ring kernels only: every tile must be a
 // full tile of a single, unsplit launch whose waves own 64 rows x (BN/2) columns, a whole number of buckets.
-bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
+// A split-K launch reduces inside the kernel (splitk_fixup) when this holds; `ws_bytes` = usable workspace bytes.  The one predicate
+// of the launch itself (launch_half) and of the plan queries that depend on it (column statistics).
+bool fixup_plan_ok(const Plan& pl, int M, int N, int64_t ws_bytes, bool defer_reduce) {
+    if (pl.ksplit <= 1 || pl.ksplit > g_fixup_max || defer_reduce || ws_bytes <= 0 || !(pl.pf == 283 || pl.pf == 244)) return false;
+    const int64_t tiles = (int64_t)((N + pl.bn - 1) / pl.bn) * ((M + pl.bm - 1) / pl.bm);
+    const int64_t frag_bytes = (int64_t)(pl.ksplit - 1) * tiles * pl.bm * pl.bn * 4;
+    return tiles <= kFixupCounters && frag_bytes <= ws_bytes && frag_bytes < 0xFFFF0000LL;
+}
+
+// (split launches: the finisher of the in-kernel reduction runs the row epilogue of an unsplit launch, statistics included)
+bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket, int64_t ws_bytes) {
     // all three: waves own 64 rows x (BN/2) columns
     const bool ring = pl.pf == 0 && pl.bm == 128, pp = pl.pf == 283 && pl.bm == 256, lc = pl.pf == 244 && pl.bm == 128;
-    return (ring || pp || lc) && (pl.bn == 160 || pl.bn == 128) && pl.ksplit == 1 && batch == 1 && bucket > 0 &&
-           M % pl.bm == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0;
+    return (ring || pp || lc) && (pl.bn == 160 || pl.bn == 128) && (pl.ksplit == 1 || fixup_plan_ok(pl, M, N, ws_bytes, false)) && batch == 1 &&
+           bucket > 0 && M % pl.bm == 0 && N % pl.bn == 0 && (pl.bn / 2) % bucket == 0;
 }
 
 // The one place that refuses a plan (heuristic or forced) whose kernel lacks an epilogue the launch asks for; nullptr = fine.
@@ -2309,7 +2406,7 @@ bool colstats_plan_ok(const Plan& pl, int M, int N, int batch, int bucket) {
 //     implement it (128x128 and 64x64 register / DMA kernels, ring tiles with TN = 2 or 4) and never with split-K -- any
 //     other kernel's plain epilogue would store [M, N] into the [M, N/2] output;
 //   * column statistics come out of the full-tile row epilogue of the two default 128-row ring kernels only.
-const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch) {
+const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch, int64_t ws_bytes) {
     if (p.act == GMD_ACT_GEGLU) {
         const bool odd_tn = pl.bn == 160 || (pl.pf >= 100 && pl.pf != 283 && pl.bm == 64 && pl.bn == 64);  // TN = 5 / ring<1,4,1,.>: TN = 1
         if (odd_tn || pl.ksplit > 1 || p.out_f32 || (pl.pf == 244 && pl.bm != 128)) return "has no GEGLU epilogue";
@@ -2317,7 +2414,7 @@ const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch) {
     if (p.colstats) {
         const bool rows_ok = !p.out_f32 && p.act != GMD_ACT_GEGLU && (p.ldc & 7) == 0 && (p.residual == nullptr || (p.ldr & 7) == 0) &&
                              (p.rowbias == nullptr || ((p.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0));
-        if (!rows_ok || !colstats_plan_ok(pl, p.M, p.N, batch, p.cs_bucket))
+        if (!rows_ok || p.defer_reduce || !colstats_plan_ok(pl, p.M, p.N, batch, p.cs_bucket, ws_bytes))
             return "cannot emit column statistics (they need the full-tile row epilogue of an unsplit 128-row ring launch: ask "
                    "gmd_gemm_colstats_plan first)";
     }
@@ -2359,7 +2456,7 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
         gmd_set_error("%s: plan %dx%d ksplit=%d cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok first)", name, pl.bm, pl.bn, pl.ksplit);
         return GMD_ERR_UNSUPPORTED;
     }
-    if (const char* why = plan_unsupported(pl, p, batch)) {
+    if (const char* why = plan_unsupported(pl, p, batch, ws ? ws_bytes : 0)) {
         gmd_set_error("%s: plan %dx%d pf=%d ksplit=%d (M=%d N=%d bucket=%d) %s", name, pl.bm, pl.bn, pl.pf, pl.ksplit, p.M, p.N, p.cs_bucket, why);
         return GMD_ERR_UNSUPPORTED;
     }
@@ -2367,6 +2464,16 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
     p.ws = (float*)ws;
     p.tile_group = CONV ? 1 : pick_tile_group(pl, p.M, p.N, p.K);  // (convolutions: neighbouring M-panels share their halo rows)
     const int gz = pl.ksplit > 1 ? pl.ksplit : batch;
+    // In-kernel split-K reduction (splitk_fixup) instead of slabs + splitk_reduce_kernel: the round-4 kernels (one workgroup per CU,
+    // wave tiles in registers), up to g_fixup_max slices (the finisher reads the other slices' fragments one after the other), the
+    // consumer of the slabs not being a fused GroupNorm (defer_reduce).  Bit-identical to the slab path (same order of additions).
+    p.fixup = 0;
+    if (fixup_plan_ok(pl, p.M, p.N, ws ? ws_bytes : 0, p.defer_reduce != 0)) {
+        const int64_t tiles = (int64_t)((p.N + pl.bn - 1) / pl.bn) * ((p.M + pl.bm - 1) / pl.bm);
+        p.fixup = 1;
+        p.fix_bytes = (unsigned)((int64_t)(pl.ksplit - 1) * tiles * pl.bm * pl.bn * 4);
+        p.fix_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + ws_bytes);  // the tail behind the usable bytes
+    }
     bool done = false;
     if (pl.pf == 244) {  // loader / consumer kernel: 4 consumer + 4 loader waves, 4-stage ring, one workgroup per CU
         if (pl.bm == 128 && pl.bn == 160) e = launch_lc<HT, CONV, 4, 5>(p, gz, s);
@@ -2421,7 +2528,7 @@ int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t
         else if (pl.bm == 64 && pl.bn == 64) e = launch_bf16<HT, CONV, 64, 64, 0>(p, gz, s);
         else { gmd_set_error("%s: tile %dx%d is not instantiated", name, pl.bm, pl.bn); return GMD_ERR_UNSUPPORTED; }
     }
-    if (e == hipSuccess && pl.ksplit > 1 && !p.defer_reduce) {
+    if (e == hipSuccess && pl.ksplit > 1 && !p.defer_reduce && !p.fixup) {
         const int64_t total = (int64_t)p.M * ((p.N + 7) / 8);
         int64_t g = (total + 255) / 256;
         if (g > 4096) g = 4096;
@@ -2478,6 +2585,12 @@ int gmd_gemm_plan_family(int family) {
     return prev;
 }
 
+int gmd_splitk_fixup_max(int max_slices) {
+    const int prev = g_fixup_max;
+    if (max_slices >= 0) g_fixup_max = max_slices > 16 ? 16 : max_slices;
+    return prev;
+}
+
 int gmd_conv_patch_override(int mode) {
     GMD_REQUIRE(mode >= 0 && mode <= 2, "gmd_conv_patch_override: mode 0, 1 or 2");
     if (!tuning_enabled()) {
@@ -2489,12 +2602,14 @@ int gmd_conv_patch_override(int mode) {
 }
 
 int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int bucket) {
+    workspace_bytes = gmd_ws_usable_bytes(workspace_bytes);  // the tail of the workspace holds the split-K arrival counters
     if (gmd_is_split(dtype)) return gmd_split_colstats_ok(M, N, K, batch, workspace_bytes, bucket);  // round 4
     if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 0;
-    return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false), M, N, batch, bucket) ? 1 : 0;
+    return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false), M, N, batch, bucket, workspace_bytes) ? 1 : 0;
 }
 
 int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4) {
+    workspace_bytes = gmd_ws_usable_bytes(workspace_bytes);  // the tail of the workspace holds the split-K arrival counters
     GMD_REQUIRE(gmd_is_half(dtype) && M > 0 && N > 0 && K > 0 && K % BK == 0 && batch > 0 && out4, "gmd_gemm_plan_info: 16-bit launches only");
     const Plan pl = make_plan(M, N, K, batch, workspace_bytes, geglu != 0);
     out4[0] = pl.bm; out4[1] = pl.bn; out4[2] = pl.pf; out4[3] = pl.ksplit;
@@ -2502,16 +2617,22 @@ int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t worksp
 }
 
 // 1 when a float32-split gmd_gemm_nt launch of these dimensions can take out_dtype = GMD_F32SA (store its result pre-split)
-int gmd_gemm_out_split_ok(int M, int N, int K, int geglu, int64_t workspace_bytes) { return gmd_split_out_ok(M, N, K, geglu, workspace_bytes); }
+int gmd_gemm_out_split_ok(int M, int N, int K, int geglu, int64_t workspace_bytes) { return gmd_split_out_ok(M, N, K, geglu, gmd_ws_usable_bytes(workspace_bytes)); }
+
+// (ws_bytes: the USABLE bytes, i.e. without the counter tail)
+static int qkv_vt_ok_usable(int dtype, int M, int N, int K, int vt_col0, int vt_tokens, int64_t ws_bytes) {
+    if (dtype == GMD_F32SW || dtype == GMD_F32SA) return gmd_split_qkv_vt_ok(M, N, K, vt_col0, vt_tokens, ws_bytes);
+    if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % 64) return 0;
+    return qkv_vt_plan_ok(make_plan(M, N, K, 1, ws_bytes, false), M, N, 1, vt_col0, vt_tokens) ? 1 : 0;
+}
 
 int gmd_gemm_qkv_vt_ok(int dtype, int M, int N, int K, int vt_col0, int vt_tokens, int64_t workspace_bytes) {
-    if (dtype == GMD_F32SW || dtype == GMD_F32SA) return gmd_split_qkv_vt_ok(M, N, K, vt_col0, vt_tokens, workspace_bytes);
-    if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % 64) return 0;
-    return qkv_vt_plan_ok(make_plan(M, N, K, 1, workspace_bytes, false), M, N, 1, vt_col0, vt_tokens) ? 1 : 0;
+    return qkv_vt_ok_usable(dtype, M, N, K, vt_col0, vt_tokens, gmd_ws_usable_bytes(workspace_bytes));
 }
 
 int gmd_gemm_qkv_vt(const void* A, const void* W, void* C, void* Vt, int dtype, int M, int N, int K, int64_t ldc, int vt_col0, int vt_tokens,
                     int64_t vt_ld, float alpha, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+    workspace_bytes = gmd_ws_usable_bytes(workspace_bytes);  // the tail of the workspace holds the split-K arrival counters
     const bool split = dtype == GMD_F32SW || dtype == GMD_F32SA;  // float32 tensors on the matrix cores, pre-split weights
     GMD_REQUIRE(gmd_is_half(dtype) || split, "gmd_gemm_qkv_vt: the 16-bit types and GMD_F32SW / GMD_F32SA only (dtype %d)", dtype);
     GMD_REQUIRE(M > 0 && N > 0 && K > 0 && K % (split ? 32 : 64) == 0, "gmd_gemm_qkv_vt: bad shape M=%d N=%d K=%d", M, N, K);
@@ -2521,7 +2642,7 @@ int gmd_gemm_qkv_vt(const void* A, const void* W, void* C, void* Vt, int dtype, 
     // pre-split operands are [hi 64 B | lo 64 B] per 32-element chunk of a row (rows are K elements here): whole 128-byte chunks only
     GMD_REQUIRE(!split || ((reinterpret_cast<uintptr_t>(W) & 127) == 0 && (dtype != GMD_F32SA || (reinterpret_cast<uintptr_t>(A) & 127) == 0)),
                 "gmd_gemm_qkv_vt: a pre-split operand must be 128-byte aligned (32-element chunks of [hi | lo])");
-    GMD_REQUIRE(gmd_gemm_qkv_vt_ok(dtype, M, N, K, vt_col0, vt_tokens, workspace ? workspace_bytes : 0), "gmd_gemm_qkv_vt: this launch cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok)");
+    GMD_REQUIRE(qkv_vt_ok_usable(dtype, M, N, K, vt_col0, vt_tokens, workspace ? workspace_bytes : 0), "gmd_gemm_qkv_vt: this launch cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok)");
     GemmParams p{};
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K;
     p.lda = K; p.ldw = K; p.ldc = ldc;
@@ -2544,6 +2665,7 @@ int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 int64_t ldw, int64_t ldc, int batch, int64_t strideA, int64_t strideW, int64_t strideC, const float* bias,
                 const float* rowbias, int rows_per_group, int64_t ldrb, const void* residual, int64_t ldr, int64_t strideR, float alpha,
                 int act, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+    workspace_bytes = gmd_ws_usable_bytes(workspace_bytes);  // the tail of the workspace holds the split-K arrival counters
     const bool split = gmd_is_split(dtype);  // float32 tensors, three float16 MFMA passes
     GMD_REQUIRE(dtype == GMD_BF16 || dtype == GMD_F16 || dtype == GMD_F32 || split, "gmd_gemm_nt: bad dtype %d", dtype);
     const bool is16 = gmd_is_half(dtype);
@@ -2693,11 +2815,12 @@ int gmd_conv3x3(const void* X, const void* Wt, void* Y, int dtype, int out_dtype
                 int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb, const void* residual,
                 float alpha, float* colstats, int colstats_bucket, void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
     return conv3x3_impl(X, Wt, Y, dtype, out_dtype, B, Hin, Win, Cin, Cout, stride, upsample, pad_mode, bias, rowbias, ldrb, residual, alpha,
-                        colstats, colstats_bucket, workspace, workspace_bytes, stream, nullptr);
+                        colstats, colstats_bucket, workspace, gmd_ws_usable_bytes(workspace_bytes), stream, nullptr);
 }
 
 int gmd_conv3x3_gn_fusable(int dtype, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample, int pad_mode, int groups,
                            int64_t workspace_bytes) {
+    workspace_bytes = gmd_ws_usable_bytes(workspace_bytes);  // the tail of the workspace holds the split-K arrival counters
     const bool split = gmd_is_split(dtype);
     if (!(gmd_is_half(dtype) || split) || B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0) return 0;
     if (!(stride == 1 || stride == 2) || (upsample && stride != 1) || !(pad_mode == 0 || (pad_mode == 1 && stride == 2 && !upsample))) return 0;
@@ -2716,6 +2839,7 @@ int gmd_conv3x3_groupnorm(const void* X, const void* Wt, void* Yraw, void* Ynorm
                           int stride, int upsample, int pad_mode, const float* bias, const float* rowbias, int64_t ldrb,
                           const void* residual, float alpha, int groups, float eps, const float* gamma, const float* beta, int silu,
                           void* workspace, int64_t workspace_bytes, gmd_stream_t stream) {
+    workspace_bytes = gmd_ws_usable_bytes(workspace_bytes);  // the tail of the workspace holds the split-K arrival counters
     GMD_REQUIRE(Ynorm && gamma && beta && groups > 0 && gmd_aligned16(Ynorm), "gmd_conv3x3_groupnorm: null or unaligned GroupNorm argument");
     const bool split = gmd_is_split(dtype);
     const GnTail gn{Ynorm, groups, eps, gamma, beta, silu};

@@ -47,7 +47,19 @@ struct GemmParams {
     void* vt_out;
     int vt_col0, vt_tokens;
     int64_t vt_ld;
+    // in-kernel split-K reduction (round 5, splitk_fixup in gemm.hip): the K slices 0 .. ksplit-2 of a tile leave their accumulator
+    // fragments in `ws` and count themselves in fix_cnt[tile]; the LAST slice (dispatched last) waits for them, adds them in slice
+    // order and runs the fused epilogue -- no slab round trip, no reduction launch.  fix_bytes: extent of the fragment area.
+    int fixup;
+    unsigned fix_bytes;
+    unsigned* fix_cnt;
 };
+
+// The last GMD_WS_TAIL bytes of a caller's workspace hold the arrival counters of the in-kernel split-K reduction (one per tile):
+// zero when the workspace is first handed to the library, left zero by every launch.  Slabs / fragments never reach into them.
+constexpr int kFixupCounters = 16384;
+constexpr int64_t kWsTail = (int64_t)kFixupCounters * 4;
+static inline int64_t gmd_ws_usable_bytes(int64_t bytes) { return bytes > kWsTail ? bytes - kWsTail : 0; }
 
 // (row tile, column tile) of linear tile index L under GemmParams::tile_group
 __device__ __forceinline__ void grouped_tile(int L, int tiles_m, int tiles_n, int group, int& mt, int& nt) {

@@ -576,10 +576,8 @@ __global__ __launch_bounds__(kThreads) void gn_slab_kernel(const SlabSource sp, 
             for (int e = 0; e < EP; ++e) {
                 float x = acc[k][e] * sp.alpha;
                 if (sp.bias) x += sp.bias[ch[k] + e];
-                if constexpr (sizeof(T) == 2) {  // ((acc*alpha + bias) + rowbias) + residual: epilogue_store8 of gemm.hip
-                    if (rb) x += rb[ch[k] + e];
-                    if (sp.residual) x += rv[e];
-                } else {                         // (acc*alpha + bias) + (residual + rowbias): splitk_reduce_f32_kernel
+                {  // (acc*alpha + bias) + (residual + rowbias): the association of EVERY epilogue of gemm.hip / gemm_split.hip (round 5:
+                   // the 16-bit reduction kernel used to add row bias and residual one after the other -- the two never meet in the UNet)
                     float add = 0.f;
                     if (sp.residual) add += rv[e];
                     if (rb) add += rb[ch[k] + e];

@@ -43,6 +43,7 @@ SIGNATURES = {
     "gmd_unpack_nchw": [P, I, L, I, I, L, P, P],
     "gmd_gemm_plan_override": [I, I, I, I],
     "gmd_gemm_plan_family": [I],
+    "gmd_splitk_fixup_max": [I],
     "gmd_gemm_nt": [P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, P, P, I, L, P, L, L, F, I, P, I, P, L, P],
     "gmd_gemm_colstats_plan": [I, I, I, I, I, L, I],
     "gmd_gemm_plan_info": [I, I, I, I, I, L, I, P],

@@ -243,7 +243,10 @@ def _stream():
 
 
 _WS = {}
-WORKSPACE_BYTES = 96 << 20
+# 96 MB of split-K scratch + the tail the library reserves for its arrival counters (gmd_hip.h "WORKSPACE CONTRACT": zero when first
+# handed over, left zero by every launch).  The same number goes to every launch AND every plan query.
+WS_TAIL_BYTES = 65536
+WORKSPACE_BYTES = (96 << 20) + WS_TAIL_BYTES
 
 
 class workspace_scope:
@@ -265,7 +268,9 @@ class workspace_scope:
 
 
 def new_workspace(device):
-    return torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    ws = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    ws[-(WS_TAIL_BYTES // 4):].zero_()  # the arrival counters of the in-kernel split-K reduction start at zero
+    return ws
 
 
 def _workspace(device):
@@ -277,7 +282,7 @@ def _workspace(device):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
-        ws = _WS[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        ws = _WS[key] = new_workspace(device)
     return ws
 
 

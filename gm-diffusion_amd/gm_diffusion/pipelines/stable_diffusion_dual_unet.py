@@ -61,6 +61,10 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
     # latents_{i+1}).  Measured on MI355X (bench.py): eager launches 3.04 vs 3.04 images/s (the host, ~10 us per launch,
     # cannot keep two streams fed); with each forward replayed from a captured HIP graph 3.04 -> 3.86 images/s.
     overlap_streams = True
+    # Launch-plan family of the two UNet forwards (hip_ops.plan_family): None = by regime -- the co-running family when the forwards
+    # overlap on two streams, the launch-by-launch plans when they share one stream; True / False pin it (bench.py pins True for
+    # its instrumented single-stream step so that it times, and compares bit for bit, the kernels the shipped path runs)
+    co_run_plans = None
     _step_probe = None  # test hook: callable(i, sdr_latents, gm_latents) after every loop iteration
 
     def __init__(self, vae, text_encoder, tokenizer, unet, gm_unet, scheduler, safety_checker, feature_extractor,
@@ -183,7 +187,7 @@ class StableDiffusionDualUNetPipeline(_GMPipelineBase):
             # two forwards in flight side by side: their contractions take the co-running plan family (fewest L2 -> LDS bytes per
             # product; -2.2 % per batch against the launch-by-launch plans, +8.6 % if the streams were serialised:
             # profiles/r05_ab_plan_default.txt), a single-stream run keeps the plans that are fastest alone
-            co_run = gm_stream is not sdr_stream
+            co_run = (gm_stream is not sdr_stream) if self.co_run_plans is None else bool(self.co_run_plans)
             if self._graphs_ok():
                 g_sdr = self.unet.graphed_forward(nb_sdr, h, w, ctx, cfg_shared=shared, co_run=co_run)
                 g_gm = self.gm_unet.graphed_forward(latents.shape[0], h, w, gm_ctx, co_run=co_run)

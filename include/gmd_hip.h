@@ -31,6 +31,7 @@ extern "C" {
 #endif
 
 #define GMD_ABI_VERSION 11
+#define GMD_WS_TAIL_BYTES 65536 /* see "WORKSPACE CONTRACT" at gmd_gemm_nt */
 
 #define GMD_OK 0
 #define GMD_ERR_INVALID 1     /* bad argument (shape / alignment / null) */
@@ -206,6 +207,14 @@ int gmd_gemm_plan_override(int bm, int bn, int pf, int ksplit);
  * local, so concurrent host threads do not see each other's choice.  GMD_PP=b / GMD_PP=1 in the environment pin 1 / 0 process-wide. */
 int gmd_gemm_plan_family(int family);
 
+/* Split-K launches of the 16-bit gmd_gemm_nt / gmd_conv3x3 with up to `max_slices` K slices reduce INSIDE the kernel (the last
+ * slice of a tile adds the others' accumulator fragments in slice order and runs the fused epilogue: no partial-sum slabs, no
+ * reduction launch); more slices, and launches whose consumer reads the slabs itself (gmd_conv3x3_groupnorm), keep the slab path.
+ * Both paths add the same partial sums in the same order: results are bit-identical.  Default 4 (GMD_SPLITK_FIXUP=<n> in the
+ * environment seeds it; 0 = slab path everywhere).  Returns the previous value; a negative argument only queries.  Process-wide:
+ * change it only while no launch is in flight (tests, A/B measurements). */
+int gmd_splitk_fixup_max(int max_slices);
+
 /* C[b] = act(alpha * A[b] @ W[b]^T + bias + rowbias + residual).
  * A: [M,K] ld lda; W: [N,K] ld ldw (both K-contiguous); C: [M,N] ld ldc, out_dtype F32 or `dtype`.
  * bias: float32 [N] or NULL.  rowbias: float32 [ceil(M/rows_per_group), ldrb] (ldrb >= N; 0 means N) or NULL, added to rows
@@ -214,7 +223,13 @@ int gmd_gemm_plan_family(int family);
  * 4 (float32) elements (ldw of a pre-split W counts k's, as for the plain matrix);
  * base pointers 16-byte aligned.  nn.Linear / conv1x1 / attention score products.
  * workspace (optional, float32 scratch of workspace_bytes): lets launches that cannot fill the chip split K
- * (deterministic slab reduction, no atomics); with NULL / too small a workspace K is not split. */
+ * (deterministic: partial sums are added in slice order, no floating-point atomics); with NULL / too small a workspace K is not split.
+ * WORKSPACE CONTRACT (ABI v11; every entry point that takes a workspace): the last GMD_WS_TAIL_BYTES of the buffer are reserved for
+ * the library's split-K arrival counters -- they must be ZERO when a buffer is first handed to the library (memset it once after
+ * allocating it) and every launch leaves them zero; only workspace_bytes - GMD_WS_TAIL_BYTES are used for partial sums, and the plan
+ * queries (gmd_gemm_colstats_plan, gmd_gemm_plan_info, gmd_gemm_qkv_vt_ok, gmd_gemm_out_split_ok, gmd_conv3x3_gn_fusable) take the
+ * same workspace_bytes the launch will get.  One workspace serves ONE stream (or one captured graph) at a time: launches that may
+ * run concurrently need workspaces of their own. */
 int gmd_gemm_nt(const void* A, const void* W, void* C, int dtype, int out_dtype,
                 int M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc,
                 int batch, int64_t strideA, int64_t strideW, int64_t strideC,

@@ -105,12 +105,16 @@ def test_pipeline_fullsize_graph_equals_eager_and_tail(sd15, res, batch, steps):
     lat = torch.randn(batch, 4, h, h, generator=g).to(DEV)
     kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=res, width=res, num_inference_steps=steps,
               guidance_scale=7.5, output_type="latent")
+    # (the plan family is pinned: captured / eager / one / two streams must run the SAME launches to be comparable bit for bit --
+    #  by default the pipeline takes the co-running family only when its two forwards overlap)
+    sd15.co_run_plans = True
     sd15.use_hip_graphs, sd15.overlap_streams = True, True
     a = sd15(**kw)
     a2 = sd15(**kw)
     sd15.use_hip_graphs, sd15.overlap_streams = False, False
     e = sd15(**kw)
     sd15.use_hip_graphs, sd15.overlap_streams = True, True
+    sd15.co_run_plans = None
     for x in (a2, e):
         assert torch.equal(a[0], x[0]) and torch.equal(a[1], x[1])
     assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
@@ -225,6 +229,7 @@ def test_sdxl_width_dual_pipeline_1024_graph_equals_eager():
         scheduler=PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1,
                                 set_alpha_to_one=False), safety_checker=None, feature_extractor=None, requires_safety_checker=False)
     pipe.set_progress_bar_config(disable=True)
+    pipe.co_run_plans = True  # the same launch plans with and without the stream overlap: the runs are compared bit for bit
     B, res = 4, 1024
     g = torch.Generator().manual_seed(12)
     pe, ne = torch.randn(B, 77, 2048, generator=g).to(DEV), torch.randn(B, 77, 2048, generator=g).to(DEV)

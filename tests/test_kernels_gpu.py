@@ -815,6 +815,32 @@ def test_colstats_from_producer_epilogue(dtype, kind):
     assert rel_err(st, ref) < 2e-6 and max_err(st[..., 0], ref[..., 0]) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,ci,co", [(4, 64, 320, 320), (8, 32, 640, 640), (4, 32, 1280, 640)])
+def test_split_launch_with_in_kernel_reduction_emits_statistics(B, H, ci, co):
+    """Round 5: under the co-running plan family the 64x64 / 32x32 convolutions of the GM UNet (and the SDR UNet's 32x32 level) run as
+    2 or 4 K slices; the last slice adds the others' fragments inside the kernel and leaves through the full-tile row epilogue, so the
+    launch emits the GroupNorm statistics like an unsplit one -- sums of the STORED values against float64, output untouched."""
+    o = ops()
+    g = torch.Generator().manual_seed(B + H + ci)
+    x = torch.randn(B, H * H, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.02).bfloat16().to(DEV)
+    bias = torch.randn(co, generator=g).to(DEV)
+    rb = torch.randn(B, co, generator=g).to(DEV)
+    with o.plan_family(1):
+        assert o.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)[3] in (2, 4)
+        y, _, _ = o.conv3x3(x, w, B, H, H, bias=bias, rowbias=rb, colstats=True)
+        plain, _, _ = o.conv3x3(x, w, B, H, H, bias=bias, rowbias=rb)
+    assert torch.equal(y, plain) and hasattr(y, "_colstats")
+    st, C = y._colstats
+    ref = _bucket_sums(y.view(-1, C), o.COLSTATS_BUCKET)
+    assert tuple(st.shape) == tuple(ref.shape) and rel_err(st, ref) < 2e-6 and max_err(st[..., 0], ref[..., 0]) < 2e-3
+    # ... and a GroupNorm fed from them equals the GroupNorm that computes its own
+    gamma, beta = torch.randn(co, generator=g).to(DEV), torch.randn(co, generator=g).to(DEV)
+    n_cs = o.groupnorm(y, B, 32, gamma, beta, 1e-5, silu=True)
+    n_own = o.groupnorm(plain, B, 32, gamma, beta, 1e-5, silu=True)
+    assert rel_err(n_cs.float(), n_own.float()) < 4e-3
+
+
 def test_colstats_only_where_the_plan_has_the_row_epilogue():
     """Small / split-K / 64x64-tile launches cannot emit statistics: the front end then attaches none (GroupNorm falls back
     to its own statistics launch), and forcing the request through the C ABI fails loudly instead of leaving them unwritten."""
@@ -824,7 +850,16 @@ def test_colstats_only_where_the_plan_has_the_row_epilogue():
     lib = _native.lib()
     code = o.dtype_code(torch.bfloat16)
     assert lib.gmd_gemm_colstats_plan(code, 32768, 320, 2880, 1, o.WORKSPACE_BYTES, 10) == 1
-    assert lib.gmd_gemm_colstats_plan(code, 2048, 1280, 11520, 1, o.WORKSPACE_BYTES, 10) == 0  # split-K
+    # split-K: since round 5 launches of up to four K slices reduce inside the kernel and their last slice runs the row epilogue,
+    # statistics included (test_split_launch_with_in_kernel_reduction_emits_statistics); the slab path (more slices, or the in-kernel
+    # reduction switched off) still cannot
+    prev = lib.gmd_splitk_fixup_max(0)
+    try:
+        assert lib.gmd_gemm_colstats_plan(code, 2048, 1280, 11520, 1, o.WORKSPACE_BYTES, 10) == 0
+    finally:
+        lib.gmd_splitk_fixup_max(prev)
+    with o.plan_family(1):
+        assert lib.gmd_gemm_colstats_plan(code, 256, 1280, 5120, 1, o.WORKSPACE_BYTES, 10) == 0  # 8 slices: slabs
     assert lib.gmd_gemm_colstats_plan(code, 512, 320, 320, 1, o.WORKSPACE_BYTES, 10) == 0      # 64x64 tiles
     assert lib.gmd_gemm_colstats_plan(code, 32768, 320, 2880, 1, o.WORKSPACE_BYTES, 32) == 0   # 80 % 32 != 0
     assert lib.gmd_gemm_colstats_plan(o.dtype_code(torch.float32), 32768, 320, 2880, 1, o.WORKSPACE_BYTES, 10) == 0

@@ -133,6 +133,7 @@ def test_graph_replay_equals_eager_and_streams():
     """Captured-graph replay, eager launches and the two-stream overlap must give bit-identical latents."""
     pipe = _dual_pipe(torch.bfloat16)
     pipe.set_progress_bar_config(disable=True)
+    pipe.co_run_plans = True  # one plan family for all four modes (by default the co-running family goes with the stream overlap)
     g = torch.Generator().manual_seed(5)
     pe, ne = torch.randn(2, 77, 64, generator=g).to(DEV), torch.randn(2, 77, 64, generator=g).to(DEV)
     lat = torch.randn(2, 4, 16, 16, generator=g).to(DEV)
@@ -171,6 +172,7 @@ def test_pipelines_share_one_side_stream_per_device():
     outs = {}
     for name, p in (("a", p1), ("b", p2)):
         p.set_progress_bar_config(disable=True)
+        p.co_run_plans = True  # the single-stream reference runs the same launch plans as the overlapped runs
         p.overlap_streams = False
         outs[name] = p(**kw)
         p.overlap_streams = True

@@ -389,3 +389,147 @@ def test_fused_qkv_projection_float32_matrix_core_path(B, tokens, C, presplit_a)
         assert torch.equal(r2[0], qk) and torch.equal(r2[1], vt)
     finally:
         o.set_f32_mode(prev)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 5: in-kernel split-K reduction (csrc/gemm.hip: splitk_fixup) and the co-running plan family (gmd_gemm_plan_family)
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def fixup_knob():
+    from gm_diffusion._native import lib
+
+    prev = lib().gmd_splitk_fixup_max(-1)
+    yield lib().gmd_splitk_fixup_max
+    lib().gmd_splitk_fixup_max(prev)
+
+
+def _tail_is_zero(ops):
+    ws = ops._workspace(torch.device("cuda", torch.cuda.current_device()))
+    return int(ws[-(ops.WS_TAIL_BYTES // 4):].view(torch.int32).abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,slices", [
+    (2048, 1280, 1280, 2),   # SDR UNet 16x16 projections: 64 tiles of 256 x 160 -> 2 slices (20 K steps)
+    (1024, 1280, 1280, 2),   # GM UNet 16x16 projections
+    (8192, 640, 2560, 2),    # 32x32 feed-forward output projection: 128 tiles
+    (2048, 1280, 5120, 4),   # 16x16 feed-forward output projection: 4 slices -- the finisher adds three fragment sets in slice order
+    (4096, 640, 2560, 4),    # GM UNet 32x32
+    (2000, 1280, 1280, 2),   # ragged last row tile: the finisher leaves through the register epilogue
+])
+def test_splitk_fixup_is_bit_identical_to_the_slab_reduction(dt, M, N, K, slices, fixup_knob):
+    """Split-K launches of the co-running plan family reduce inside the kernel (the last K slice of a tile waits for the others'
+    accumulator fragments, adds them in slice order and runs the fused epilogue) instead of writing float32 slabs for a reduction
+    launch.  Same partial sums, same order of additions: the outputs must be BIT-identical to the slab path, launch after launch
+    (the arrival counters in the workspace tail clean themselves), and float32-grade against the float64 product."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).to(dt).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(dt).to(DEV)
+    with ops.plan_family(1):
+        assert ops.gemm_plan_info(dt, M, N, K)[2:] == (283, slices)
+        fixup_knob(0)
+        ref = ops.gemm_nt(a, w, bias=b, residual=r)
+        fixup_knob(4)
+        outs = [ops.gemm_nt(a, w, bias=b, residual=r) for _ in range(3)]
+    torch.cuda.synchronize()
+    for y in outs:
+        assert torch.equal(y, ref)
+    assert _tail_is_zero(ops)
+    exact = a.double().cpu() @ w.double().cpu().T + b.double().cpu() + r.double().cpu()
+    assert _rel(ref.cpu(), exact) < (6e-3 if dt == torch.bfloat16 else 8e-4)
+
+
+@pytest.mark.parametrize("B,H,ci,co,slices", [(8, 32, 640, 640, 2), (4, 32, 1280, 640, 4), (8, 16, 1280, 1280, 4), (4, 64, 320, 320, 2)])
+def test_splitk_fixup_conv3x3_bit_identical(B, H, ci, co, slices, fixup_knob):
+    """The same for the convolutions (patch-resident kernel and the per-tap ping-pong kernel share the fix-up), with the two epilogues
+    a ResnetBlock2D uses (conv1 = bias + time-embedding row bias, conv2 = bias + residual) and with all three (every epilogue adds
+    them as (acc * alpha + bias) + (residual + row bias))."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(B * H + ci)
+    x = torch.randn(B, H * H, ci, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(co, 9 * ci, generator=g) * 0.02).bfloat16().to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    rb = torch.randn(B, co, generator=g).to(DEV)
+    r = torch.randn(B, H * H, co, generator=g).bfloat16().to(DEV)
+    with ops.plan_family(1):
+        assert ops.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)[3] == slices
+        for kw, exact in ((dict(bias=b, rowbias=rb), True), (dict(bias=b, residual=r), True), (dict(bias=b, rowbias=rb, residual=r), True)):
+            fixup_knob(0)
+            ref = ops.conv3x3(x, w, B, H, H, **kw)[0]
+            fixup_knob(4)
+            outs = [ops.conv3x3(x, w, B, H, H, **kw)[0] for _ in range(2)]
+            torch.cuda.synchronize()
+            for y in outs:
+                assert torch.equal(y, ref) if exact else _rel(y, ref) < 2e-3
+            assert _rel(ref, _conv_ref(x, w, B, H, H, **kw)) < 6e-3
+    assert _tail_is_zero(ops)
+
+
+def test_splitk_fixup_under_a_second_streams_load(fixup_knob):
+    """The finisher spins on an arrival counter while the producers of its tile run on other CUs.  Replayed from a captured graph
+    beside a second stream that keeps the chip busy with its own split launches (the shipped regime: two UNet forwards side by side),
+    every replay must give the quiet run's bits, and the counters must end at zero."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(77)
+    shapes = [(2048, 1280, 1280), (1024, 1280, 5120), (8192, 640, 2560), (4096, 640, 640 * 4)]
+    prob = []
+    for M, N, K in shapes:
+        prob.append((torch.randn(M, K, generator=g).bfloat16().to(DEV), (torch.randn(N, K, generator=g) * 0.03).bfloat16().to(DEV),
+                     torch.randn(N, generator=g).to(DEV)))
+    fixup_knob(4)
+
+    def run_all():
+        return [ops.gemm_nt(a, w, bias=b) for a, w, b in prob]
+
+    with ops.plan_family(1):
+        quiet = run_all()
+        torch.cuda.synchronize()
+        side = ops.side_stream(DEV)
+        gr, ws = torch.cuda.CUDAGraph(), ops.new_workspace(torch.device(DEV))
+        with ops.workspace_scope(ws), torch.cuda.graph(gr):
+            outs = run_all()
+        ws2 = ops.new_workspace(torch.device(DEV))
+        for it in range(40):
+            with torch.cuda.stream(side), ops.workspace_scope(ws2):
+                for _ in range(2):
+                    run_all()
+            gr.replay()
+            if it % 8 == 7:
+                torch.cuda.synchronize()
+                for y, q in zip(outs, quiet):
+                    assert torch.equal(y, q), f"replay {it}"
+    torch.cuda.synchronize()
+    for t in (ws, ws2):
+        assert int(t[-(ops.WS_TAIL_BYTES // 4):].view(torch.int32).abs().max()) == 0
+
+
+def test_plan_families_agree_and_are_scoped_to_the_thread():
+    """gmd_gemm_plan_family: family 1 (co-running: 256-row tiles + K slices) and family 0 (launch-by-launch) compute the same
+    product up to float32 summation order; the choice is the calling thread's and the scope restores it."""
+    import threading
+
+    from gm_diffusion import hip_ops as ops
+    from gm_diffusion._native import lib
+
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 2048, 1280, 1280
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16().to(DEV)
+    assert lib().gmd_gemm_plan_family(-1) == 0
+    p0 = ops.gemm_plan_info(torch.bfloat16, M, N, K)
+    y0 = ops.gemm_nt(a, w)
+    seen = {}
+    with ops.plan_family(1):
+        p1 = ops.gemm_plan_info(torch.bfloat16, M, N, K)
+        y1 = ops.gemm_nt(a, w)
+        t = threading.Thread(target=lambda: seen.setdefault("other", lib().gmd_gemm_plan_family(-1)))
+        t.start(); t.join()
+    assert lib().gmd_gemm_plan_family(-1) == 0 and seen["other"] == 0
+    assert p0 != p1 and p1[:3] == (256, 160, 283) and p1[3] > 1
+    assert _rel(y1, y0) < 2e-3 and _rel(y0.cpu(), a.double().cpu() @ w.double().cpu().T) < 6e-3
