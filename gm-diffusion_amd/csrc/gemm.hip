@@ -273,6 +273,21 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
         grem = mw - g0 * p.rows_per_group;
     }
     float cs[(NCOL + 63) / 64] = {}, cq[(NCOL + 63) / 64] = {};  // column sums of this wave tile (p.colstats only)
+    // Round 5: ALL of the wave tile's residual rows are requested up front (TM / 2 x ITER 16-byte loads per lane: 40 registers at
+    // TN = 5, free now that the fragments are dead), so their L2 / HBM latency runs under the staging of the accumulators instead of
+    // being exposed once per 32-row half behind the wave barrier (the short-K projections are prologue / epilogue-bound).
+    uint4 resv[TM / 2][ITER];
+    if (p.residual) {
+#pragma unroll
+        for (int h = 0; h < TM / 2; ++h)
+#pragma unroll
+            for (int t = 0; t < ITER; ++t) {
+                const int idx = lane + 64 * t;
+                const int r = idx / CH, c = idx - r * CH;
+                if (32 * CH % 64 != 0 && r >= 32) continue;
+                resv[h][t] = *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)(mw + h * 32 + r) * p.ldr + nw + c * 8);
+            }
+    }
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
@@ -293,7 +308,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
             float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.residual) {
-                const uint4 w = *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
+                const uint4 w = resv[h][t];
                 const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) Half<HT>::unpack2(ww[e], add[2 * e], add[2 * e + 1]);
@@ -1054,12 +1069,32 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
         unsigned long long dreal1;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dreal1)::"memory");
         dg[7] = dreal1 - dreal0;  // 100 MHz ticks
+#ifdef GMD_WG_TRACE
+        // with the occupancy trace: one DETAIL record per wave into the CU's trace array (kind | 0x80), so that the loop split is
+        // available for the launches of a whole pipeline run, co-running with the other stream (tools/cu_occupancy.py --pp-detail)
+        if (lane == 0 && g_wg_trace != nullptr) {
+            GmdWgTraceHeader* h = g_wg_trace;
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            const unsigned shard = ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u) + ((hw >> 8) & 15u);
+            unsigned long long* counters = reinterpret_cast<unsigned long long*>(h + 1);
+            const unsigned long long i = __hip_atomic_fetch_add(counters + 16ull * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (i < h->capacity) {
+                uint4* rec = reinterpret_cast<uint4*>(counters + 16ull * h->shards) + 2ull * (shard * h->capacity + i);
+                // consumers: reads + wait | barrier after R | mfma issue | barrier after C;  loaders: dma issue | loader barrier | - | vmcnt wait
+                const unsigned a0 = (unsigned)(loader ? dg[1] : dg[0]), a1 = (unsigned)dg[3], a2 = (unsigned)(loader ? 0 : dg[4]), a3 = (unsigned)(loader ? dg[6] : dg[5]);
+                rec[0] = make_uint4(a0, a1, a2, a3);
+                rec[1] = make_uint4(hw, (xcc & 15u) | ((unsigned)((WGK_PP | (CONV ? WGK_CONV_BIT : 0)) | 0x80) << 8) | ((unsigned)wid << 16), (unsigned)nk | ((unsigned)TN << 16),
+                                    (unsigned)(dprev - dtime0));
+            }
+        }
+#else
         if (p.ws && lane == 0) {
             unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + ((size_t)blockIdx.x * (NCONS + LW) + wid) * 10;
             for (int k = 0; k < 8; ++k) o[k] = dg[k];
             o[8] = dprev - dtime0;
             o[9] = (unsigned long long)nk;
         }
+#endif
     };
 #define PP_STAMP(k) { const unsigned long long t_ = stamp_now(); dg[k] += t_ - dprev; dprev = t_; }
 #else
@@ -2177,6 +2212,7 @@ int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e
 // it with gmd_gemm_plan_family(); GMD_PP=b / GMD_PP=1 pin family 1 / 0 for the whole process (A/B runs), read once at load time.
 const int g_family_pin = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b') ? 1 : ((e && e[0] == '1') ? 0 : -1); }();
 thread_local int t_plan_family = 0;
+const int g_family1_min_nk = [] { const char* e = getenv("GMD_MIN_NK"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();  // A/B only
 const int g_family1_ks_cap = [] { const char* e = getenv("GMD_KS_CAP"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();  // A/B only
 // In-kernel split-K reduction up to this many K slices (0 = off: slabs + reduction launch everywhere).  GMD_SPLITK_FIXUP=<n>, read once.
 int g_fixup_max = [] { const char* e = getenv("GMD_SPLITK_FIXUP"); return e ? atoi(e) : 4; }();  // gmd_splitk_fixup_max() changes it in-process
@@ -2255,7 +2291,7 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
                 const int64_t t = mt256 * (N / bn);
                 int ks = t >= 256 ? 1 : (int)((256 + t / 2) / t);
                 if (ks > g_family1_ks_cap) ks = g_family1_ks_cap;
-                while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
+                while (ks > 1 && (nk / ks < g_family1_min_nk || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
                 pl = Plan{256, bn, 283, ks};
             }
         } else if (pair_tiles) {

@@ -18,7 +18,9 @@ ap.add_argument("--only", default="gemm,conv,ln,gn,attn")
 ap.add_argument("--force", default="")
 ap.add_argument("--reps", type=int, default=24)
 ap.add_argument("--sets", type=int, default=6)
+ap.add_argument("--family", type=int, default=0, help="launch-plan family (gmd_gemm_plan_family): 1 = the co-running family of the dual pipeline")
 a = ap.parse_args()
+lib().gmd_gemm_plan_family(a.family)
 if a.force:
     lib().gmd_gemm_plan_override(*[int(v) for v in a.force.split(",")])
 dev = "cuda"

@@ -26,6 +26,8 @@ ap.add_argument("--iters", type=int, default=10, help="loop iterations analysed 
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--out", default="")
 ap.add_argument("--dump", default="", help="save the raw records of the analysed window (npz)")
+ap.add_argument("--pp-detail", action="store_true",
+                help="(library built with -DGMD_PP_DIAG=1 as well) only report where the waves of gemm_pp_kernel spend their K loop WHILE CO-RUNNING")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 B, steps = a.batch, 50
@@ -50,6 +52,7 @@ def build():
     p = StableDiffusionDualUNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, gm_unet=gm, scheduler=sched, safety_checker=None,
                                         feature_extractor=None, requires_safety_checker=False)
     p.set_progress_bar_config(disable=True)
+    p.co_run_plans = True  # the serialised pass runs the SAME launches (the co-running plan family) as the shipped two-stream pass
     for m in (unet, gm):
         m._stamp_buf = torch.zeros(steps + 1, 16, dtype=torch.int64, device=dev)
         m._stamp_row = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -239,9 +242,56 @@ def kind_durations(d, qmap, s_tab):
     return out
 
 
+def pp_detail(rec, qmap, lines, label):
+    """detail records of the stamped gemm_pp_kernel (kind | 0x80): per wave the cycle sums of its K-loop segments"""
+    tag = (rec[:, 2] >> np.uint64(32)).astype(np.int64)
+    kind = (tag >> 8) & 255
+    m = (kind & 0x80) != 0
+    r = rec[m]
+    if len(r) == 0:
+        return
+    a0 = (r[:, 0] & np.uint64(0xffffffff)).astype(np.float64); a1 = (r[:, 0] >> np.uint64(32)).astype(np.float64)
+    a2 = (r[:, 1] & np.uint64(0xffffffff)).astype(np.float64); a3 = (r[:, 1] >> np.uint64(32)).astype(np.float64)
+    hw = (r[:, 2] & np.uint64(0xffffffff)).astype(np.int64); tg = tag[m]
+    q = (((hw >> 30) & 3) * 4 + ((hw >> 6) & 3)) * 8 + ((hw >> 24) & 7)
+    wid = (tg >> 16) & 255; conv = ((tg >> 8) & 64) != 0
+    nk = (r[:, 3] & np.uint64(0xffff)).astype(np.int64); tn = ((r[:, 3] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64)
+    tot = (r[:, 3] >> np.uint64(32)).astype(np.float64)
+    lines.append(f"== gemm_pp_kernel K-loop split, {label} (stamped build: every stamp adds ~40 cycles; shares, not times): shader cycles per K step and wave")
+    lines.append("   stream kind  TN  K steps  waves | consumers: reads+wait  barrier(R)  mfma issue  barrier(C)  = loop | loaders: dma issue  barrier  vmcnt wait")
+    for strm in ("sdr", "gm"):
+        for cv in (False, True):
+            for t in np.unique(tn):
+                for k in np.unique(nk):
+                    sel = (np.array([qmap.get(int(x), "?") for x in q]) == strm) & (conv == cv) & (tn == t) & (nk == k) & (nk > 0)
+                    if sel.sum() < 512:
+                        continue
+                    c = sel & (wid < 8); l = sel & (wid >= 8)
+                    f = lambda x, mm: (x[mm] / nk[mm]).mean() if mm.any() else float("nan")
+                    lines.append(f"   {strm:4s} {'conv' if cv else 'gemm'}  {t:2d}  {k:7d}  {int(sel.sum()):6d} | {f(a0, c):8.0f} {f(a1, c):10.0f} {f(a2, c):10.0f} {f(a3, c):10.0f}  = {f(tot, c):6.0f} | "
+                                 f"{f(a0, l):8.0f} {f(a1, l):8.0f} {f(a3, l):8.0f}")
+
+
+def drop_detail(rec):
+    kind = ((rec[:, 2] >> np.uint64(40)) & np.uint64(255)).astype(np.int64)
+    return rec[(kind & 0x80) == 0]
+
+
 lines = []
 p = build()
 rec, s_tab, g_tab, t_un = traced_run(p, True)
+if a.pp_detail:
+    d = decode(drop_detail(rec))
+    qmap = stream_of_queues(d, s_tab, g_tab)
+    pp_detail(rec, qmap, lines, "two streams (shipped)")
+    rec2, s2, g2, _ = traced_run(p, False)
+    q2 = {int(x): "sdr" for x in np.unique(decode(drop_detail(rec2))["q"])}
+    pp_detail(rec2, q2, lines, "streams serialised (both forwards on one queue, listed as sdr)")
+    txt = "\n".join(lines)
+    print(txt)
+    if a.out:
+        open(a.out, "w").write(txt + "\n")
+    sys.exit(0)
 d = decode(rec)
 qmap = stream_of_queues(d, s_tab, g_tab)
 lines.append(f"trace overhead: loop period {t_un:.1f} us untraced (same diagnostic library, trace pointer null) -> {(s_tab[IT1, 0] - s_tab[IT0, 0]) / (IT1 - IT0) / 100:.1f} us traced")
