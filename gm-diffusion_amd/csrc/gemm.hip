@@ -2212,8 +2212,6 @@ int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e
 // it with gmd_gemm_plan_family(); GMD_PP=b / GMD_PP=1 pin family 1 / 0 for the whole process (A/B runs), read once at load time.
 const int g_family_pin = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b') ? 1 : ((e && e[0] == '1') ? 0 : -1); }();
 thread_local int t_plan_family = 0;
-const int g_family1_min_nk = [] { const char* e = getenv("GMD_MIN_NK"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();  // A/B only
-const int g_family1_ks_cap = [] { const char* e = getenv("GMD_KS_CAP"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 16 ? 16 : v); }();  // A/B only
 // In-kernel split-K reduction up to this many K slices (0 = off: slabs + reduction launch everywhere).  GMD_SPLITK_FIXUP=<n>, read once.
 int g_fixup_max = [] { const char* e = getenv("GMD_SPLITK_FIXUP"); return e ? atoi(e) : 4; }();  // gmd_splitk_fixup_max() changes it in-process
 inline bool big_tiles() { return (g_family_pin >= 0 ? g_family_pin : t_plan_family) == 1; }
@@ -2290,8 +2288,8 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
             } else if (bn && M >= 256) {
                 const int64_t t = mt256 * (N / bn);
                 int ks = t >= 256 ? 1 : (int)((256 + t / 2) / t);
-                if (ks > g_family1_ks_cap) ks = g_family1_ks_cap;
-                while (ks > 1 && (nk / ks < g_family1_min_nk || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
+                if (ks > 8) ks = 8;
+                while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
                 pl = Plan{256, bn, 283, ks};
             }
         } else if (pair_tiles) {

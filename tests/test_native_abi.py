@@ -137,3 +137,30 @@ def test_host_rgbe_run_length_encoder_equals_oracle():
     n = ctypes.c_int64(0)
     assert lib().gmd_rgbe_rle_encode(px.ctypes.data, 2, 16, out.ctypes.data, 8, ctypes.addressof(n)) == 1  # GMD_ERR_INVALID
     assert b"smaller than gmd_rgbe_rle_bound" in lib().gmd_last_error()
+
+
+def test_no_swizzled_packed_f32_next_to_an_exec_write():
+    """Round-4 fault guard, wired into the suite: every kernel is compiled to gfx950 assembly and scanned for a
+    swizzled packed-float32 instruction (`v_pk_{add,mul,fma}_f32 ... op_sel:[..]`) within six instructions of an EXEC write -- the
+    pattern whose low result lost an addend in lanes 48..63 in 1 launch of 200-1500.  `make lint` keeps a
+    stamp (build/lint.ok) that is redone whenever a source, a header or the lint itself changes, so this is a no-op after
+    `__graft_entry__.build()` and ~2.5 minutes of hipcc on a tree whose kernels changed since."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "gm-diffusion_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "lint"], capture_output=True, text=True)
+    assert r.returncode == 0, "assembly lint failed:\n" + r.stdout[-3000:] + r.stderr[-2000:]
+    assert os.path.exists(os.path.join(csrc, "build", "lint.ok"))
+
+
+def test_lint_recognises_the_faulty_pattern(tmp_path):
+    """The lint must actually fire on the instruction sequence of the faulty round-4 build (its regular expressions, not hipcc)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("lint_pk", os.path.join(ROOT, "tools", "lint_pk_opsel_exec.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    bad = ["v_pk_add_f32 v[82:83], v[118:119], v[84:85] op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_add_f32 v[84:85], v[116:117], v[84:85]",
+           "v_cmp_gt_u32_e32 vcc, s0, v123", "s_and_saveexec_b64 s[0:1], vcc"]
+    assert m.PK.match(bad[0]) and not m.PK.match(bad[1]) and m.EXEC_W.match(bad[3]) and not m.EXEC_W.match(bad[2])
+    assert not m.PK.match("v_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0]")  # the low-register broadcast is not the pattern
