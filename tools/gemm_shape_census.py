@@ -25,12 +25,11 @@ def timed(key, fn):
     return out
 
 
-def gemm_nt(a, w, bias=None, rowbias=None, rows_per_group=0, residual=None, alpha=1.0, act=ops.ACT_NONE, out_dtype=None, out=None, ldc=None, colstats=False):
+def gemm_nt(a, w, bias=None, residual=None, act=ops.ACT_NONE, **kw):
     batch = a.shape[0] if a.dim() == 3 else (w.shape[0] if w.dim() == 3 else 1)
     mode = "geglu" if act == ops.ACT_GEGLU else ("res" if residual is not None else ("bias" if bias is not None else "plain"))
     key = ("gemm_nt", a.shape[-2], w.shape[-2], a.shape[-1], batch, mode)
-    return timed(key, lambda: orig_gemm(a, w, bias=bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=residual, alpha=alpha, act=act,
-                                        out_dtype=out_dtype, out=out, ldc=ldc, colstats=colstats))
+    return timed(key, lambda: orig_gemm(a, w, bias=bias, residual=residual, act=act, **kw))
 
 
 def conv3x3(x, w, B, H, W, **kw):
@@ -56,6 +55,8 @@ for m in (unet, gm):
     m.set_timestep(501)
 x8 = unet.pack_input(lat, dup=1)
 x4 = gm.pack_input((lat, lat), dup=1)
+from gm_diffusion._native import lib
+lib().gmd_gemm_plan_family(int(os.environ.get("GMD_ONE_FAMILY", "1")))  # the co-running plan family: what the shipped two-stream pipeline launches
 for rep in range(3):
     ACTIVE[0] = rep == 2
     torch.cuda._sleep(int(2e8)) if rep == 2 else None  # host head start: the event pairs must not include waits for the host
@@ -70,4 +71,4 @@ tot = {k: sum(r["total_us"] for r in rows if r["kind"] == k) for k in ("gemm_nt"
 for r in sorted(rows, key=lambda r: -r["total_us"]):
     r["share_of_kind"] = round(r["total_us"] / tot[r["kind"]], 4)
     print(json.dumps(r))
-print(json.dumps(dict(totals_us=tot, note="one loop iteration: SDR forward (batch 8, CFG shared prefix) + GM forward (batch 4), eager, single stream")))
+print(json.dumps(dict(totals_us=tot, note="one loop iteration: SDR forward (batch 8, CFG shared prefix) + GM forward (batch 4), eager, single stream, co-running plan family")))

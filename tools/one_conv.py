@@ -6,6 +6,8 @@ for p in (ROOT, os.path.join(ROOT, "gm-diffusion_amd")):
     sys.path.insert(0, p)
 import torch
 from gm_diffusion import hip_ops as ops
+from gm_diffusion._native import lib
+lib().gmd_gemm_plan_family(int(os.environ.get("GMD_ONE_FAMILY", "0")))  # 1 = the co-running plan family of the dual pipeline
 B, H, W, ci, co = [int(v) for v in (sys.argv[1:6] if len(sys.argv) > 5 else (8, 64, 64, 320, 320))]
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 g = torch.Generator().manual_seed(0)

@@ -2,6 +2,8 @@ import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gm-diffusion_amd"))
 import torch
 from gm_diffusion import hip_ops as ops
+from gm_diffusion._native import lib
+lib().gmd_gemm_plan_family(int(os.environ.get("GMD_ONE_FAMILY", "0")))  # 1 = the co-running plan family of the dual pipeline
 M, N, K = [int(v) for v in sys.argv[1:4]]
 mode = sys.argv[4] if len(sys.argv) > 4 else "bias"
 g = torch.Generator().manual_seed(0)
