@@ -470,6 +470,40 @@ def test_splitk_fixup_conv3x3_bit_identical(B, H, ci, co, slices, fixup_knob):
     assert _tail_is_zero(ops)
 
 
+@pytest.mark.parametrize("kind,shape", [("gemm", (2048, 1280, 10240)), ("gemm", (1024, 1280, 5120)), ("conv", (8, 16, 1280, 1280)), ("conv", (8, 16, 2560, 1280))])
+def test_splitk_fixup_loader_consumer_kernel_bit_identical(kind, shape, fixup_knob):
+    """The launch-by-launch plan family splits K too (loader / consumer kernel, 128-row tiles, 4 consumer waves): its K slices take the
+    same in-kernel reduction -- bit-identical to the slab path there as well (what the VAE and every single-stream caller run)."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(sum(shape))
+    if kind == "gemm":
+        M, N, K = shape
+        a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.03).bfloat16().to(DEV)
+        b = torch.randn(N, generator=g).to(DEV)
+        r = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+        plan = ops.gemm_plan_info(torch.bfloat16, M, N, K)
+        run = lambda: ops.gemm_nt(a, w, bias=b, residual=r)
+    else:
+        B, H, ci, co = shape
+        x = torch.randn(B, H * H, ci, generator=g).bfloat16().to(DEV)
+        w = (torch.randn(co, 9 * ci, generator=g) * 0.02).bfloat16().to(DEV)
+        b = torch.randn(co, generator=g).to(DEV)
+        rb = torch.randn(B, co, generator=g).to(DEV)
+        plan = ops.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)
+        run = lambda: ops.conv3x3(x, w, B, H, H, bias=b, rowbias=rb)[0]
+    assert plan[2] == 244 and 2 <= plan[3] <= 4, plan  # the loader / consumer kernel with K slices
+    fixup_knob(0)
+    ref = run()
+    fixup_knob(4)
+    outs = [run() for _ in range(3)]
+    torch.cuda.synchronize()
+    for y in outs:
+        assert torch.equal(y, ref)
+    assert _tail_is_zero(ops)
+
+
 def test_splitk_fixup_under_a_second_streams_load(fixup_knob):
     """The finisher spins on an arrival counter while the producers of its tile run on other CUs.  Replayed from a captured graph
     beside a second stream that keeps the chip busy with its own split launches (the shipped regime: two UNet forwards side by side),
