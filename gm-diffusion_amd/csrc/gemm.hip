@@ -1300,12 +1300,39 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
 #endif
         if (!late) seg_barrier();
     }
+#if defined(GMD_PP_DIAG) && defined(GMD_WG_TRACE)
+    // phase record of the workgroup (wave 0, lane 0), written where the kernel ends: 100 MHz ticks kernel entry -> K loop | K loop |
+    // barrier + in-kernel reduction | epilogue (to the last store ISSUED) -- tools/cu_occupancy.py --pp-detail
+    unsigned long long ph_sync = 0;
+    auto real_now = [&]() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; };
+    auto phase_emit = [&]() {
+        if (wid != 0 || lane != 0 || g_wg_trace == nullptr || nk <= 0) return;
+        const unsigned long long t_end = real_now();
+        GmdWgTraceHeader* h = g_wg_trace;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        const unsigned shard = ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u) + ((hw >> 8) & 15u);
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(h + 1);
+        const unsigned long long i2 = __hip_atomic_fetch_add(counters + 16ull * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (i2 < h->capacity) {
+            uint4* rec = reinterpret_cast<uint4*>(counters + 16ull * h->shards) + 2ull * (shard * h->capacity + i2);
+            rec[0] = make_uint4((unsigned)(dreal0 - gmd_wg_trace_scope_.t0), (unsigned)dg[7], (unsigned)(ph_sync - (dreal0 + dg[7])), (unsigned)(t_end - ph_sync));
+            rec[1] = make_uint4(hw, (xcc & 15u) | ((unsigned)((WGK_PP | (CONV ? WGK_CONV_BIT : 0)) | 0x80) << 8) | (0xFFu << 16), (unsigned)nk | ((unsigned)TN << 16),
+                                (gridDim.x * gridDim.z) | ((unsigned)p.ksplit << 20) | (p.residual ? (1u << 28) : 0u) | (p.fixup ? (1u << 29) : 0u));
+        }
+    };
+#define PP_PHASE_SYNC() ph_sync = real_now()
+#define PP_PHASE_EMIT() phase_emit()
+#else
+#define PP_PHASE_SYNC()
+#define PP_PHASE_EMIT()
+#endif
     __syncthreads();  // every wave (loaders included) is done with the K-loop stages: the strips below overwrite them
     GemmParams q = p;
     if (p.fixup) {  // in-kernel split-K reduction: the producer slices leave here, the last slice goes on as an unsplit launch
         if (!splitk_fixup<TM, TN, NCONS>(p, acc, ks, wid, lane)) return;
         q.ksplit = 1;
     }
+    PP_PHASE_SYNC();
     const bool rows_ok = !q.out_f32 && q.ksplit <= 1 && q.act != GMD_ACT_GEGLU && m0 + BM <= q.M && n0 + BN <= q.N && (q.ldc & 7) == 0 &&
                          (q.sC & 7) == 0 && (q.residual == nullptr || ((q.ldr & 7) == 0 && (q.sR & 7) == 0)) &&
                          (q.rowbias == nullptr || ((q.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.rowbias) & 15) == 0)) &&
@@ -1315,12 +1342,14 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
             (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0) {
             constexpr int kStripG = 32 * (TN * 8 + 4);
             epilogue_rows_geglu<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripG, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
+            PP_PHASE_EMIT();
             return;
         }
     }
     if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
         constexpr int kStripS = 32 * (TN * 16 + 4);
         epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
+        PP_PHASE_EMIT();
         return;
     }
     if (rows_ok) {
@@ -1330,8 +1359,11 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
     } else {
         epilogue_regs<HT, TM, TN>(q, acc, m0 + wr * 64, n0 + wc * (TN * 16), frow, fq, z, ks);
     }
+    PP_PHASE_EMIT();
 }
 #undef PP_STAMP
+#undef PP_PHASE_SYNC
+#undef PP_PHASE_EMIT
 
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel, loader / consumer form (round 4) for launches that have about ONE tile per CU (256 tiles of 128 x 160 or
@@ -2223,6 +2255,7 @@ int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e
 // it with gmd_gemm_plan_family(); GMD_PP=b / GMD_PP=1 pin family 1 / 0 for the whole process (A/B runs), read once at load time.
 const int g_family_pin = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b') ? 1 : ((e && e[0] == '1') ? 0 : -1); }();
 thread_local int t_plan_family = 0;
+const bool g_f1_bn128 = [] { const char* e = getenv("GMD_F1_BN128"); return !(e && e[0] == '0'); }();  // GMD_F1_BN128=0: A/B
 // In-kernel split-K reduction up to this many K slices (0 = off: slabs + reduction launch everywhere).  GMD_SPLITK_FIXUP=<n>, read once.
 int g_fixup_max = [] { const char* e = getenv("GMD_SPLITK_FIXUP"); return e ? atoi(e) : 4; }();  // gmd_splitk_fixup_max() changes it in-process
 inline bool big_tiles() { return (g_family_pin >= 0 ? g_family_pin : t_plan_family) == 1; }
@@ -2230,7 +2263,7 @@ inline bool big_tiles() { return (g_family_pin >= 0 ? g_family_pin : t_plan_fami
 // Tile / split-K selection.  All SD-1.5 channel widths (320, 640, 1280, 2560, 5120, 10240) are multiples of
 // 160, the VAE widths (128, 256, 512) of 128.  Launches that would leave most of the 256 CUs idle and have a
 // deep K (the 8x8 / 16x16 UNet levels: K up to 23040) are split along K.
-Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles) {
+Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles, bool want_cs = false) {
     Plan pl{64, 64, 0, 1};  // pf 0 = LDS-DMA pipeline (fastest measured); 1/2 = register-staged fallbacks
     if (M >= 96 && N >= 96) {
         pl.bm = 128;
@@ -2297,11 +2330,19 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
             if (pair_tiles) {
                 if (M >= 256 && N % 128 == 0) pl = Plan{256, 128, 283, 1};  // GEGLU pairs value / gate tiles: no K slices
             } else if (bn && M >= 256) {
-                const int64_t t = mt256 * (N / bn);
-                int ks = t >= 256 ? 1 : (int)((256 + t / 2) / t);
-                if (ks > 8) ks = 8;
-                while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
-                pl = Plan{256, bn, 283, ks};
+                auto slices = [&](int bnc) {
+                    const int64_t t = mt256 * (N / bnc);
+                    int ks = t >= 256 ? 1 : (int)((256 + t / 2) / t);
+                    if (ks > 8) ks = 8;
+                    while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
+                    return ks;
+                };
+                int bnc = bn;
+                // 128-column tiles where they still fit ONE round of workgroups: their row segments are whole 128-byte lines (a
+                // 160-column tile shares every third line of a row with its neighbour) and there are a quarter more of them
+                // (not for a launch that is to emit GroupNorm statistics: their 10-channel buckets need 80-column wave tiles)
+                if (g_f1_bn128 && !want_cs && bn == 160 && N % 128 == 0 && mt256 * (N / 128) * slices(128) <= 256) bnc = 128;
+                pl = Plan{256, bnc, 283, slices(bnc)};
             }
         } else if (pair_tiles) {
             if (M >= 256 && N % 128 == 0 && ((nk >= 20 && M >= 512) || (nk >= 10 && M >= 8192))) pl = Plan{256, 128, 283, 1};
@@ -2496,7 +2537,7 @@ template <typename HT, bool CONV>
 int launch_half(GemmParams p, int batch, void* ws, int64_t ws_bytes, hipStream_t s, const char* name) {
     constexpr bool kTune = std::is_same<HT, bf16_t>::value;
     hipError_t e = hipSuccess;
-    const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU);
+    const Plan pl = make_plan(p.M, p.N, p.K, batch, ws ? ws_bytes : 0, p.act == GMD_ACT_GEGLU, p.colstats != nullptr);
     if (p.vt_out && !qkv_vt_plan_ok(pl, p.M, p.N, batch, p.vt_col0, p.vt_tokens)) {
         gmd_set_error("%s: plan %dx%d ksplit=%d cannot write transposed V tiles (ask gmd_gemm_qkv_vt_ok first)", name, pl.bm, pl.bn, pl.ksplit);
         return GMD_ERR_UNSUPPORTED;
@@ -2650,7 +2691,7 @@ int gmd_gemm_colstats_plan(int dtype, int M, int N, int K, int batch, int64_t wo
     workspace_bytes = gmd_ws_usable_bytes(workspace_bytes);  // the tail of the workspace holds the split-K arrival counters
     if (gmd_is_split(dtype)) return gmd_split_colstats_ok(M, N, K, batch, workspace_bytes, bucket);  // round 4
     if (!gmd_is_half(dtype) || M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 0;
-    return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false), M, N, batch, bucket, workspace_bytes) ? 1 : 0;
+    return colstats_plan_ok(make_plan(M, N, K, batch, workspace_bytes, false, true), M, N, batch, bucket, workspace_bytes) ? 1 : 0;
 }
 
 int gmd_gemm_plan_info(int dtype, int M, int N, int K, int batch, int64_t workspace_bytes, int geglu, int* out4) {

@@ -827,10 +827,12 @@ def test_split_launch_with_in_kernel_reduction_emits_statistics(B, H, ci, co):
     bias = torch.randn(co, generator=g).to(DEV)
     rb = torch.randn(B, co, generator=g).to(DEV)
     with o.plan_family(1):
-        assert o.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)[3] in (2, 4)
+        assert o.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)[3] in (2, 3, 4)  # (the statistics launch itself keeps 160-column tiles: 2 or 4)
         y, _, _ = o.conv3x3(x, w, B, H, H, bias=bias, rowbias=rb, colstats=True)
         plain, _, _ = o.conv3x3(x, w, B, H, H, bias=bias, rowbias=rb)
-    assert torch.equal(y, plain) and hasattr(y, "_colstats")
+    # (the statistics launch keeps 160-column tiles, the plain one may take 128-column tiles with another number of K slices: the
+    #  same product up to float32 summation order)
+    assert hasattr(y, "_colstats") and rel_err(y.float(), plain.float()) < 4e-3
     st, C = y._colstats
     ref = _bucket_sums(y.view(-1, C), o.COLSTATS_BUCKET)
     assert tuple(st.shape) == tuple(ref.shape) and rel_err(st, ref) < 2e-6 and max_err(st[..., 0], ref[..., 0]) < 2e-3

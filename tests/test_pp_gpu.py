@@ -430,7 +430,8 @@ def test_splitk_fixup_is_bit_identical_to_the_slab_reduction(dt, M, N, K, slices
     b = torch.randn(N, generator=g).to(DEV)
     r = torch.randn(M, N, generator=g).to(dt).to(DEV)
     with ops.plan_family(1):
-        assert ops.gemm_plan_info(dt, M, N, K)[2:] == (283, slices)
+        plan = ops.gemm_plan_info(dt, M, N, K)
+        assert plan[0] == 256 and plan[2] == 283 and 2 <= plan[3] <= min(slices, 4), plan  # (128-column tiles where one round suffices: fewer slices)
         fixup_knob(0)
         ref = ops.gemm_nt(a, w, bias=b, residual=r)
         fixup_knob(4)
@@ -457,7 +458,7 @@ def test_splitk_fixup_conv3x3_bit_identical(B, H, ci, co, slices, fixup_knob):
     rb = torch.randn(B, co, generator=g).to(DEV)
     r = torch.randn(B, H * H, co, generator=g).bfloat16().to(DEV)
     with ops.plan_family(1):
-        assert ops.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)[3] == slices
+        assert 2 <= ops.gemm_plan_info(torch.bfloat16, B * H * H, co, 9 * ci)[3] <= slices
         for kw, exact in ((dict(bias=b, rowbias=rb), True), (dict(bias=b, residual=r), True), (dict(bias=b, rowbias=rb, residual=r), True)):
             fixup_knob(0)
             ref = ops.conv3x3(x, w, B, H, H, **kw)[0]
@@ -565,5 +566,5 @@ def test_plan_families_agree_and_are_scoped_to_the_thread():
         t = threading.Thread(target=lambda: seen.setdefault("other", lib().gmd_gemm_plan_family(-1)))
         t.start(); t.join()
     assert lib().gmd_gemm_plan_family(-1) == 0 and seen["other"] == 0
-    assert p0 != p1 and p1[:3] == (256, 160, 283) and p1[3] > 1
+    assert p0 != p1 and p1[0] == 256 and p1[2] == 283 and p1[3] > 1
     assert _rel(y1, y0) < 2e-3 and _rel(y0.cpu(), a.double().cpu() @ w.double().cpu().T) < 6e-3

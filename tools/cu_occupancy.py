@@ -246,7 +246,7 @@ def pp_detail(rec, qmap, lines, label):
     """detail records of the stamped gemm_pp_kernel (kind | 0x80): per wave the cycle sums of its K-loop segments"""
     tag = (rec[:, 2] >> np.uint64(32)).astype(np.int64)
     kind = (tag >> 8) & 255
-    m = (kind & 0x80) != 0
+    m = ((kind & 0x80) != 0) & (((tag >> 16) & 255) != 255)
     r = rec[m]
     if len(r) == 0:
         return
@@ -272,6 +272,32 @@ def pp_detail(rec, qmap, lines, label):
                                  f"{f(a0, l):8.0f} {f(a1, l):8.0f} {f(a3, l):8.0f}")
 
 
+def pp_phases(rec, lines, label):
+    """phase records of gemm_pp_kernel workgroups (wave 0; wid field 0xFF), 100 MHz ticks: kernel entry -> K loop | K loop | barrier +
+    in-kernel reduction | epilogue up to the last store issued"""
+    tag = (rec[:, 2] >> np.uint64(32)).astype(np.int64)
+    ph = rec[((((tag >> 8) & 255) & 0x80) != 0) & (((tag >> 16) & 255) == 255)]
+    if len(ph) == 0:
+        return
+    f = lambda col, hi: ((ph[:, col] >> np.uint64(32)) if hi else (ph[:, col] & np.uint64(0xffffffff))).astype(np.int64)
+    pro, loop, sync, epi = f(0, 0) / 100.0, f(0, 1) / 100.0, f(1, 0) / 100.0, f(1, 1) / 100.0
+    ptag = f(2, 1)
+    conv = ((ptag >> 8) & 64) != 0
+    nk, tn = f(3, 0) & 0xffff, (f(3, 0) >> 16) & 0xffff
+    g = f(3, 1)
+    grid, ksl, res, fix = g & 0xfffff, (g >> 20) & 255, (g >> 28) & 1, (g >> 29) & 1
+    lines.append(f"== gemm_pp_kernel workgroup phases, {label}: median us of wave 0 (entry -> K loop | K loop, stamped: ~10 % long | barrier + in-kernel reduction | epilogue to the last store issued)")
+    lines.append("   kind  TN  K steps  grid  slices res fixup  workgroups |  prologue     loop     sync  epilogue |    sum")
+    seen = {}
+    for i in range(len(ph)):
+        seen.setdefault((bool(conv[i]), int(tn[i]), int(nk[i]), int(grid[i]), int(ksl[i]), int(res[i]), int(fix[i])), []).append(i)
+    for key in sorted(seen, key=lambda k: -len(seen[k]))[:30]:
+        ii = np.array(seen[key])
+        cv, t, k, gg, ks_, r_, fx = key
+        m = [float(np.median(x[ii])) for x in (pro, loop, sync, epi)]
+        lines.append(f"   {'conv' if cv else 'gemm'}  {t:2d}  {k:7d}  {gg:4d}  {ks_:6d} {r_:3d} {fx:5d}  {len(ii):10d} | {m[0]:8.2f} {m[1]:8.2f} {m[2]:8.2f} {m[3]:8.2f} | {sum(m):6.2f}")
+
+
 def drop_detail(rec):
     kind = ((rec[:, 2] >> np.uint64(40)) & np.uint64(255)).astype(np.int64)
     return rec[(kind & 0x80) == 0]
@@ -284,6 +310,7 @@ if a.pp_detail:
     d = decode(drop_detail(rec))
     qmap = stream_of_queues(d, s_tab, g_tab)
     pp_detail(rec, qmap, lines, "two streams (shipped)")
+    pp_phases(rec, lines, "two streams (shipped)")
     rec2, s2, g2, _ = traced_run(p, False)
     q2 = {int(x): "sdr" for x in np.unique(decode(drop_detail(rec2))["q"])}
     pp_detail(rec2, q2, lines, "streams serialised (both forwards on one queue, listed as sdr)")
