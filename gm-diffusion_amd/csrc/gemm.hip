@@ -254,9 +254,14 @@ __device__ __forceinline__ void epilogue_cols_vt(const GemmParams& p, const f32x
     }
 }
 
-template <typename HT, int TM, int TN>
-__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
-                                              int z) {
+// (PLAIN: the launch has no activation -- every projection and convolution of the UNet but the time-embedding MLP.  A compile-time
+// fact for the item loop: with the activation chosen by a run-time switch per element, the SiLU and quick-GELU bodies (exp, IEEE
+// division) sat in all ten unrolled items of a wave tile -- ~600 instructions, 3.6 KB of code per item -- and although their
+// branches were never taken, FETCHING that code once per wave tile cost ~0.55 us per item: in-kernel stamps put 5.5 of the 7.2 us
+// epilogue of a K = 320 projection there, with the stores, the bias and the residual all ruled out one by one (round 5).)
+template <typename HT, int TM, int TN, bool PLAIN>
+__device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
+                                                   int z) {
     static_assert(TM % 2 == 0, "halves of two 16-row tiles");
     if (p.vt_out && nw >= p.vt_col0) {  // wave-uniform: a V column tile of a fused Q|K|V projection
         epilogue_cols_vt<HT, TM, TN>(p, acc, strip, mw, nw, lane);
@@ -276,20 +281,52 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
     // Round 5: ALL of the wave tile's residual rows are requested up front (TM / 2 x ITER 16-byte loads per lane: 40 registers at
     // TN = 5, free now that the fragments are dead), so their L2 / HBM latency runs under the staging of the accumulators instead of
     // being exposed once per 32-row half behind the wave barrier (the short-K projections are prologue / epilogue-bound).
-    uint4 resv[TM / 2][ITER];
-    if (p.residual) {
+#if defined(GMD_PP_DIAG) && defined(GMD_WG_TRACE)
+    unsigned long long et[6] = {0, 0, 0, 0, 0, 0};
+    int eti = 0;
+#define EPI_STAMP() { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (eti < 6) et[eti++] = t_; }
+#else
+#define EPI_STAMP()
+#endif
+    EPI_STAMP()
+    static_assert(NCOL / 4 <= 32, "one bias float4 per strip row");
+    // Round 5: the residual rows (or, for a launch with a row bias and no residual, the row bias) of a 32-row half are requested BEFORE
+    // that half's accumulators are staged, so their L2 / HBM latency runs under the LDS writes and the wave barrier instead of being
+    // exposed item by item behind the previous item's store.  (One half at a time, two 16-byte values per item: both halves up front
+    // spill in the 256 x 160 kernels once the item loop is a single basic block.)
+    uint4 resv[2][ITER];
+    // Round 5: the bias of this wave's columns goes into the strip's PAD columns once (row j holds float4 j of the bias: the four
+    // floats behind the NCOL data columns of a row are never written by the staging below).  Loaded inside the item loop it cost
+    // ONE exposed global-load round trip per item -- the loads cannot move above the previous item's store (they may alias for all
+    // the compiler knows) -- ten serialised ~0.6 us trips per wave tile: in-kernel stamps put 6.2 of the 7.6 us epilogue of a
+    // K = 320 projection there (tools/dbg/pp_phase_probe.py).
+    if (lane < NCOL / 4)
+        *reinterpret_cast<float4*>(strip + lane * ROWF + NCOL) = p.bias ? *reinterpret_cast<const float4*>(p.bias + nw + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool rb_pre = PLAIN && p.rowbias != nullptr && p.residual == nullptr;  // row bias alone (conv1 of a ResnetBlock2D): prefetched per half
 #pragma unroll
-        for (int h = 0; h < TM / 2; ++h)
+    for (int h = 0; h < TM / 2; ++h) {
+        if (PLAIN && p.residual) {  // (the activation instances -- time-embedding MLP, text encoder: tiny launches -- load in place)
 #pragma unroll
             for (int t = 0; t < ITER; ++t) {
                 const int idx = lane + 64 * t;
                 const int r = idx / CH, c = idx - r * CH;
                 if (32 * CH % 64 != 0 && r >= 32) continue;
-                resv[h][t] = *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)(mw + h * 32 + r) * p.ldr + nw + c * 8);
+                resv[0][t] = *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)(mw + h * 32 + r) * p.ldr + nw + c * 8);
             }
-    }
+        }
+        if (rb_pre) {
 #pragma unroll
-    for (int h = 0; h < TM / 2; ++h) {
+            for (int t = 0; t < ITER; ++t) {
+                const int idx = lane + 64 * t;
+                const int r = idx / CH, c = idx - r * CH;
+                if (32 * CH % 64 != 0 && r >= 32) continue;
+                const int ro = h * 32 + r;
+                const int grp = p.rows_per_group >= 64 ? g0 + (grem + ro >= p.rows_per_group ? 1 : 0) : (mw + ro) / p.rows_per_group;
+                const float* rb = p.rowbias + (int64_t)grp * p.ldrb + nw + c * 8;
+                resv[0][t] = __builtin_bit_cast(uint4, *reinterpret_cast<const float4*>(rb));
+                resv[1][t] = __builtin_bit_cast(uint4, *reinterpret_cast<const float4*>(rb + 4));
+            }
+        }
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -297,6 +334,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
                 *reinterpret_cast<float4*>(strip + (i2 * 16 + frow) * ROWF + j * 16 + fq * 4) =
                     make_float4(acc[2 * h + i2][j][0], acc[2 * h + i2][j][1], acc[2 * h + i2][j][2], acc[2 * h + i2][j][3]);
         __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS: only the compiler must not reorder across this point
+        EPI_STAMP()
 #pragma unroll
         for (int t = 0; t < ITER; ++t) {
             const int idx = lane + 64 * t;
@@ -308,28 +346,38 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
             float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.residual) {
-                const uint4 w = resv[h][t];
+                const uint4 w = PLAIN ? resv[0][t] : *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
                 const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) Half<HT>::unpack2(ww[e], add[2 * e], add[2 * e + 1]);
             }
-            if (p.rowbias) {
+            if (rb_pre) {
+                const float4 t0 = __builtin_bit_cast(float4, resv[0][t]), t1 = __builtin_bit_cast(float4, resv[1][t]);
+                add[0] += t0.x; add[1] += t0.y; add[2] += t0.z; add[3] += t0.w; add[4] += t1.x; add[5] += t1.y; add[6] += t1.z; add[7] += t1.w;
+            } else if (p.rowbias) {  // row bias AND residual (never in the UNet): loaded in place
                 const int ro = h * 32 + r;  // row offset inside the wave tile
                 const int grp = p.rows_per_group >= 64 ? g0 + (grem + ro >= p.rows_per_group ? 1 : 0) : m / p.rows_per_group;
                 const float* rb = p.rowbias + (int64_t)grp * p.ldrb + n;
                 const float4 t0 = *reinterpret_cast<const float4*>(rb), t1 = *reinterpret_cast<const float4*>(rb + 4);
                 add[0] += t0.x; add[1] += t0.y; add[2] += t0.z; add[3] += t0.w; add[4] += t1.x; add[5] += t1.y; add[6] += t1.z; add[7] += t1.w;
             }
-            float bz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                const float4 t0 = *reinterpret_cast<const float4*>(p.bias + n), t1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-                bz[0] = t0.x; bz[1] = t0.y; bz[2] = t0.z; bz[3] = t0.w; bz[4] = t1.x; bz[5] = t1.y; bz[6] = t1.z; bz[7] = t1.w;
-            }
+            const float4 b0 = *reinterpret_cast<const float4*>(strip + (2 * c) * ROWF + NCOL), b1 = *reinterpret_cast<const float4*>(strip + (2 * c + 1) * ROWF + NCOL);
+            const float bz[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], PLAIN ? GMD_ACT_NONE : p.act);  // same association as epilogue_regs
             HT* o = (HT*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
             const uint4 packed = make_uint4(Half<HT>::pack2(v[0], v[1]), Half<HT>::pack2(v[2], v[3]), Half<HT>::pack2(v[4], v[5]), Half<HT>::pack2(v[6], v[7]));
+#if defined(GMD_EPI_NOSTORE)  // timing experiment only (tools/dbg): the epilogue without its global stores (results are wrong)
+            if (packed.x == 0x12345678u && packed.y == 0x9abcdef0u) *reinterpret_cast<uint4*>(o) = packed;
+#elif defined(GMD_EPI_NT)     // timing experiment only: non-temporal stores
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4, packed), reinterpret_cast<u32x4*>(o));
+#else
             *reinterpret_cast<uint4*>(o) = packed;
+#endif
+            // (one item at a time: without this fence the compact PLAIN body lets the scheduler pull every item's strip reads to the
+            //  front -- 70 spilled registers in the 256 x 160 kernels, one workgroup per CU instead of two in the ring kernel)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             if (p.colstats) {  // the values as stored (rounded) go back to the strip for the column pass below
                 const unsigned pw[4] = {packed.x, packed.y, packed.z, packed.w};
                 float rv[8];
@@ -340,16 +388,38 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (
             }
         }
         __builtin_amdgcn_wave_barrier();
+        EPI_STAMP()
         if (p.colstats) {  // lane -> column (and column 64 + lane): 32 conflict-free reads each, fixed order (gemm_shared.h)
             colstats_pass<NCOL, ROWF>(strip, lane, cs, cq);
             __builtin_amdgcn_wave_barrier();
         }
     }
+#if defined(GMD_PP_DIAG) && defined(GMD_WG_TRACE)
+    if (threadIdx.x == 0 && g_wg_trace != nullptr) {  // epilogue split of wave 0 (wid field 0xFE): start | staged h0 | items h0 | staged h1 | items h1
+        GmdWgTraceHeader* hh = g_wg_trace;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        const unsigned shard = ((((xcc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u) + ((hw >> 8) & 15u);
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(hh + 1);
+        const unsigned long long i2 = __hip_atomic_fetch_add(counters + 16ull * shard, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (i2 < hh->capacity) {
+            uint4* rec = reinterpret_cast<uint4*>(counters + 16ull * hh->shards) + 2ull * (shard * hh->capacity + i2);
+            rec[0] = make_uint4((unsigned)(et[1] - et[0]), (unsigned)(et[2] - et[1]), (unsigned)(et[3] - et[2]), (unsigned)(et[4] - et[3]));
+            rec[1] = make_uint4(hw, (xcc & 15u) | ((unsigned)(WGK_PP | 0x80) << 8) | (0xFEu << 16), (unsigned)TN << 16, p.residual ? 1u : 0u);
+        }
+    }
+#endif
+#undef EPI_STAMP
     // producer statistics for a following GroupNorm: {sum, sum of squares} of the STORED values over this wave tile's TM*16 = 64
     // rows (one row block of the statistics) and each bucket of cs_bucket adjacent columns
     if (p.colstats)
         colstats_store<NCOL, ROWF>(strip, lane, cs, cq, p.cs_bucket,
                                    p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket) * 2);
+}
+
+template <typename HT, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane, int z) {
+    if (p.act == GMD_ACT_NONE) epilogue_rows_impl<HT, TM, TN, true>(p, acc, strip, mw, nw, lane, z);
+    else epilogue_rows_impl<HT, TM, TN, false>(p, acc, strip, mw, nw, lane, z);
 }
 
 // Split-K variant of epilogue_rows: the raw float32 partial sums of a full tile go to this slice's slab as whole row
