@@ -182,9 +182,11 @@ __device__ __forceinline__ void epilogue_cols_vt_f32(const GemmParams& p, const 
     }
 }
 
-template <int TM, int TN, bool SLAB>
-__device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
-                                                  int z, int ks) {
+// (PLAIN: no activation -- a compile-time fact for the item loop, as in epilogue_rows of gemm.hip: with the run-time switch the
+// never-taken SiLU / quick-GELU bodies made every unrolled item hundreds of instructions and the epilogue instruction-fetch-bound.)
+template <int TM, int TN, bool SLAB, bool PLAIN>
+__device__ __forceinline__ void epilogue_rows_f32_impl(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane,
+                                                       int z, int ks) {
     static_assert(TM % 2 == 0, "halves of two 16-row tiles");
     if (!SLAB && p.vt_out && nw >= p.vt_col0) {  // wave-uniform: a V column tile of a fused Q|K|V projection
         epilogue_cols_vt_f32<TM, TN>(p, acc, strip, mw, nw, lane);
@@ -238,7 +240,7 @@ __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32
                 bz[0] = t0.x; bz[1] = t0.y; bz[2] = t0.z; bz[3] = t0.w;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], p.act);  // same association as epilogue_regs_f32
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] * p.alpha + bz[e] + add[e], PLAIN ? GMD_ACT_NONE : p.act);  // same association as epilogue_regs_f32
             if (p.c_split) gmd_store_split4((float*)p.C, (int64_t)m * p.ldc + n, v[0], v[1], v[2], v[3]);  // (batch 1, ldc = row length: host-checked)
             else *reinterpret_cast<float4*>((float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             if (p.colstats)  // the stored values go back to the strip for the column pass below
@@ -255,6 +257,12 @@ __device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32
     if (!SLAB && p.colstats)
         colstats_store<NCOL, ROWF>(strip, lane, cs, cq, p.cs_bucket,
                                    p.colstats + ((int64_t)(mw / (TM * 16)) * (p.N / p.cs_bucket) + nw / p.cs_bucket) * 2);
+}
+
+template <int TM, int TN, bool SLAB>
+__device__ __forceinline__ void epilogue_rows_f32(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane, int z, int ks) {
+    if (SLAB || p.act == GMD_ACT_NONE) epilogue_rows_f32_impl<TM, TN, SLAB, true>(p, acc, strip, mw, nw, lane, z, ks);
+    else epilogue_rows_f32_impl<TM, TN, SLAB, false>(p, acc, strip, mw, nw, lane, z, ks);
 }
 
 // GEGLU (GEGLU.forward of diffusers: value * gelu_erf(gate)): the W rows are interleaved at load time in 16-row [value | gate]
