@@ -418,7 +418,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, const f3
 
 template <typename HT, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const f32x4 (&acc)[TM][TN], float* strip, int mw, int nw, int lane, int z) {
-    if (p.act == GMD_ACT_NONE) epilogue_rows_impl<HT, TM, TN, true>(p, acc, strip, mw, nw, lane, z);
+    if (__builtin_expect(p.act == GMD_ACT_NONE, 1)) epilogue_rows_impl<HT, TM, TN, true>(p, acc, strip, mw, nw, lane, z);  // (hot: laid out next to the K loop)
     else epilogue_rows_impl<HT, TM, TN, false>(p, acc, strip, mw, nw, lane, z);
 }
 
@@ -493,24 +493,39 @@ __device__ __forceinline__ bool splitk_fixup(const GemmParams& p, f32x4 (&acc)[T
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)last && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();
+    // two fragment rows (2 x TN 16-byte loads per lane) in flight at a time: the sc1 loads come from the fabric (~1 us each way), so
+    // the number of load -> wait round trips is what this costs -- TM / 2 of them per slice; all TM rows at once would spill
+    static_assert(TM % 2 == 0, "fragment rows are fetched in pairs");
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        f32x4 t[TN];
+    for (int i = 0; i < TM; i += 2) {
+        f32x4 t[2][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            t[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wave_off + (unsigned)(i * TN + j) * 1024u, 0, 16 /* sc1 */));
-        for (int s = 1; s < last; ++s) {
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                t[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * slice_bytes + wave_off + (unsigned)(i * TN + j) * 1024u, 0, 16));
+                t[ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wave_off + (unsigned)((i + ii) * TN + j) * 1024u, 0, 16 /* sc1 */));
+        for (int s = 1; s < last; ++s) {  // (3 or 4 slices: one row of the pair at a time -- TN more values in flight, not 2 TN)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                f32x4 u[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    u[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)s * slice_bytes + wave_off + (unsigned)((i + ii) * TN + j) * 1024u, 0, 16));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    t[ii][j] += u[j];
+                    asm volatile("" : "+v"(t[ii][j])::"memory");
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            acc[i][j] = t[j] + acc[i][j];
-            // one row of fragments in flight at a time (TN x 4 temporaries, not TM x TN x 4: spills): the sums of this row exist
-            // before any load of the next row is issued
-            asm volatile("" : "+v"(acc[i][j])::"memory");
-        }
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i + ii][j] = t[ii][j] + acc[i + ii][j];
+                // (the sums of this pair of rows exist before any load of the next pair is issued: bounded registers)
+                asm volatile("" : "+v"(acc[i + ii][j])::"memory");
+            }
     }
     if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch
     return true;
@@ -1042,7 +1057,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 : 1) vo
         epilogue_rows_slab<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
         return;
     }
-    if (rows_ok) {
+    if (__builtin_expect(rows_ok, 1)) {
         __syncthreads();  // every wave is done with the K-loop stages: the strips below overwrite them
         constexpr int kStrip = 32 * (TN * 16 + 4);  // floats per wave
         static_assert((size_t)NWAVES * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
@@ -1416,13 +1431,13 @@ __global__ __launch_bounds__(768, 3) void gemm_pp_kernel(const GemmParams p) {
             return;
         }
     }
-    if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
+    if (__builtin_expect(q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0, 0)) {
         constexpr int kStripS = 32 * (TN * 16 + 4);
         epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
         PP_PHASE_EMIT();
         return;
     }
-    if (rows_ok) {
+    if (__builtin_expect(rows_ok, 1)) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
         static_assert((size_t)NCONS * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
         epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
@@ -1676,13 +1691,13 @@ __global__ __launch_bounds__(512, 2) void gemm_lc_kernel(const GemmParams p) {
         }
     }
     if constexpr (TM == 4) {
-        if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
+        if (__builtin_expect(q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0, 0)) {
             constexpr int kStripS = 32 * (TN * 16 + 4);
             epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, ks);
             return;
         }
     }
-    if (rows_ok) {
+    if (__builtin_expect(rows_ok, 1)) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
         static_assert((size_t)NCONS * kStrip * 4 <= (size_t)NST * kStage, "epilogue strips must fit in the ring stages");
         epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * (TM * 16), n0 + wc * (TN * 16), lane, z);
@@ -1953,12 +1968,12 @@ __global__ __launch_bounds__(768, 3) void conv_patch_kernel(const GemmParams p) 
                          (q.residual == nullptr || (q.ldr & 7) == 0) &&
                          (q.rowbias == nullptr || ((q.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.rowbias) & 15) == 0)) &&
                          (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0;
-    if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
+    if (__builtin_expect(q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0, 0)) {
         constexpr int kStripS = 32 * (TN * 16 + 4);
         epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
         return;
     }
-    if (rows_ok) {
+    if (__builtin_expect(rows_ok, 1)) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
         epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
     } else {
@@ -2181,12 +2196,12 @@ __global__ __launch_bounds__(768, 3) void conv_patch_cont_kernel(const GemmParam
                          (q.residual == nullptr || (q.ldr & 7) == 0) &&
                          (q.rowbias == nullptr || ((q.ldrb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.rowbias) & 15) == 0)) &&
                          (reinterpret_cast<uintptr_t>(q.bias) & 15) == 0;
-    if (q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0) {
+    if (__builtin_expect(q.ksplit > 1 && m0 + BM <= q.M && n0 + BN <= q.N && (q.N & 3) == 0, 0)) {
         constexpr int kStripS = 32 * (TN * 16 + 4);
         epilogue_rows_slab<TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStripS, m0 + wr * 64, n0 + wc * (TN * 16), lane, ks);
         return;
     }
-    if (rows_ok) {
+    if (__builtin_expect(rows_ok, 1)) {
         constexpr int kStrip = 32 * (TN * 16 + 4);
         epilogue_rows<HT, TM, TN>(q, acc, reinterpret_cast<float*>(smem) + wid * kStrip, m0 + wr * 64, n0 + wc * (TN * 16), lane, z);
     } else {
