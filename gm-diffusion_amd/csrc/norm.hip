@@ -3,6 +3,8 @@
 // fixed (deterministic) reduction order everywhere -- no float atomics.
 #include "gmd_common.h"
 #include <math.h>
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -153,16 +155,121 @@ __device__ __forceinline__ void store_vec_maybe_split(T* Y, int64_t e, const flo
     }
 }
 
-template <typename T, bool SPLIT_OUT = false>
+
+// The apply pass of gn_apply_ws_kernel / gn_apply_cs_kernel.  A workgroup owns `span` = 256 * U consecutive 16-byte vectors of one
+// sample (U in {2, 4, 6, 10}, chosen by the host: gn_apply_span_u), thread t the vectors first + t + 256 u; channel chunk = index mod CV, scale /
+// shift per channel in LDS.  Round 5: a thread's loads are requested in two halves around the statistics fold (X does not
+// depend on it, see gn_rows_apply) and there is no loop -- the old form kept ONE 16-byte load per thread outstanding behind a 64-bit modulo (2048
+// waves x 1 KB = 2 MB in flight on the whole chip: 1.9-3.4 TB/s alone, less beside a second stream).  A load is skipped only where
+// the WHOLE wave is past the end (scalar branch); inside a partly valid wave the index is clamped -- a load inside a per-lane
+// `if (i < vend)` is waited for right there, one at a time.
+typedef unsigned gn_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ void gn_unpack16(const uint4& r, float (&v)[Elem<T>::kVec]) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __uint_as_float(w[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Half<T>::unpack2(w[k], v[2 * k], v[2 * k + 1]);
+    }
+}
+// loads u in [U0, U1) of a thread's vectors.  Unconditional, the index clamped to the workgroup's last vector: a load inside an
+// `if (i < vend)` is waited for right there, and even a wave-uniform skip splits the code into blocks at whose edges the
+// compiler's wait-count pass falls back to vmcnt(0) (only the last workgroup of a sample can have a thread past the end)
+template <typename T, int U0, int U1, int U>
+__device__ __forceinline__ void gn_rows_request(const T* Xb, int vbeg, int vend, uint4 (&raw)[U]) {
+    constexpr int V = Elem<T>::kVec;
+    const int vlast = vend > 0 ? vend - 1 : 0;
+#pragma unroll
+    for (int u = U0; u < U1; ++u) {
+        const int i = vbeg + u * kThreads;
+        raw[u] = *reinterpret_cast<const uint4*>(Xb + (int64_t)(i < vlast ? i : vlast) * V);
+    }
+}
+// The first half of a thread's vectors is requested before the statistics are folded, the second half here, right behind the
+// prologue's last barrier and in front of the first half's arithmetic and stores: the workgroups of a launch run in lock-step (all
+// resident at once), and with every load up front the launch was a read phase followed by a write phase (10.3 us for 42 MB without
+// SiLU where LayerNorm's small workgroups take 6.7); now the second half's reads overlap the first half's writes.  X and Y are NOT
+// declared restrict here: the compiler must keep the second half's loads above the first half's stores.
+template <bool SPLIT_OUT, typename T, int U>
+__device__ __forceinline__ void gn_rows_apply(const T* Xb, T* Yb, const float* ss, int CV, int vbeg, int vend, int silu, uint4 (&raw)[U]) {
+    constexpr int V = Elem<T>::kVec;
+    int c = vbeg % CV;
+    const int step = kThreads % CV;
+    gn_rows_request<T, U / 2, U, U>(Xb, vbeg, vend, raw);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(Yb, 0, vend * 16, 0x00020000);  // (vend < 2^28: host-checked)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = vbeg + u * kThreads;
+        float xv[V];
+        gn_unpack16<T>(raw[u], xv);
+        const float* q = ss + (size_t)c * V * 2;
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {
+            const float4 t = *reinterpret_cast<const float4*>(q + 2 * j);
+            xv[j] = xv[j] * t.x + t.y;
+            xv[j + 1] = xv[j + 1] * t.z + t.w;
+        }
+        if (silu) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) xv[j] = silu_f(xv[j]);
+        }
+        if constexpr (SPLIT_OUT) {
+            if (i < vend) store_vec_maybe_split<SPLIT_OUT>(Yb, (int64_t)i * V, xv);
+        } else {
+            // range-checked buffer store (vectors >= vend are dropped by the hardware): no branch around the store, so the whole pass
+            // is one basic block and the compiler counts the waits (behind per-lane `if (i < vend)` blocks it waited for ALL earlier
+            // stores before the last vectors' arithmetic)
+            gn_u32x4 o;
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(xv[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = Half<T>::pack2(xv[2 * k], xv[2 * k + 1]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, i * 16, 0, 0);
+        }
+        c += step;
+        if (c >= CV) c -= CV;
+    }
+}
+// vectors per thread of an apply launch over B samples of `nvec` 16-byte vectors: the largest instantiated count (2, 4, 6, 10) that
+// still leaves >= 512 workgroups
+static inline int gn_apply_span_u(int B, int64_t nvec) {
+    static const int forced = [] { const char* e = getenv("GMD_GN_U"); return e ? atoi(e) : 0; }();  // (experiments)
+    int64_t u = forced > 0 ? forced : (nvec * B) / (512 * (int64_t)kThreads);
+    return u >= 10 ? 10 : u >= 6 ? 6 : u >= 4 ? 4 : 2;
+}
+// f(IntC<U>) for the instantiated U
+template <typename F>
+static inline void gn_for_u(int u, F&& f) {
+    if (u == 10) f(std::integral_constant<int, 10>{});
+    else if (u == 6) f(std::integral_constant<int, 6>{});
+    else if (u == 4) f(std::integral_constant<int, 4>{});
+    else f(std::integral_constant<int, 2>{});
+}
+
+template <typename T, bool SPLIT_OUT, int U>
 __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t HW, int C, int G,
                                                                int nsplit, float eps, const float* __restrict__ ws,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int silu) {
+                                                               int silu, int span) {
     GMD_WG_TRACE_SCOPE(WGK_GN_APPLY_WS);
     constexpr int V = Elem<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) float ss[];  // [C][2] = {scale, shift}
     __shared__ float s_mean[64], s_rstd[64];
     const int b = blockIdx.y, cpg = C / G;
+    const int CV = C / V;
+    const T* Xb = X + ((int64_t)b * HW) * C;
+    T* Yb = Y + ((int64_t)b * HW) * C;
+    const int vtot = (int)HW * CV;  // (< 2^28: host-checked)
+    const int vbeg = (int)blockIdx.x * span + (int)threadIdx.x;
+    const int vend = (int)blockIdx.x * span + span < vtot ? (int)blockIdx.x * span + span : vtot;
+    uint4 xv[U];
+    gn_rows_request<T, 0, U / 2, U>(Xb, vbeg, vend, xv);
     for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
         const int g = g0 + (int)threadIdx.x / 8, sub = threadIdx.x & 7;
         double s = 0.0, s2 = 0.0;
@@ -191,28 +298,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
         ss[2 * c + 1] = beta[c] - s_mean[g] * sc;
     }
     __syncthreads();
-    const int CV = C / V;
-    const int64_t per = (HW + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < HW ? r0 + per : HW;
-    const T* Xb = X + ((int64_t)b * HW) * C;
-    T* Yb = Y + ((int64_t)b * HW) * C;
-    for (int64_t i = r0 * CV + threadIdx.x; i < r1 * CV; i += kThreads) {
-        const int chunk = (int)(i % CV);
-        float v[V];
-        load_vec(Xb + i * V, v);
-        const float* q = ss + (size_t)chunk * V * 2;
-#pragma unroll
-        for (int j = 0; j < V; j += 2) {
-            const float4 t = *reinterpret_cast<const float4*>(q + 2 * j);
-            v[j] = v[j] * t.x + t.y;
-            v[j + 1] = v[j + 1] * t.z + t.w;
-        }
-        if (silu) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) v[j] = silu_f(v[j]);
-        }
-        store_vec_maybe_split<SPLIT_OUT>(Yb, i * V, v);
-    }
+    gn_rows_apply<SPLIT_OUT, T, U>(Xb, Yb, ss, CV, vbeg, vend, silu, xv);
 }
 
 // Apply with the statistics taken from the PRODUCER of X: the GEMM / convolution that wrote X left {sum, sum of squares} per
@@ -221,17 +307,25 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
 // of two producers' outputs (the up blocks' skip connections): channels < Ca take their sums from sa [rows/64][Ca/bucket][2],
 // the others from sb [rows/64][(C-Ca)/bucket][2].  Same fold as gn_apply_ws_kernel (8 lanes per group over a fixed strided
 // subset of its (row block, bucket) items, double accumulation, fixed-order shuffle tree): deterministic.
-template <typename T, bool SPLIT_OUT = false>
+template <typename T, bool SPLIT_OUT, int U>
 __global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t HW, int C, int G,
                                                                float eps, const float* __restrict__ sa, int Ca,
                                                                const float* __restrict__ sb, int bucket,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int silu) {
+                                                               int silu, int span) {
     GMD_WG_TRACE_SCOPE(WGK_GN_APPLY_CS);
     constexpr int V = Elem<T>::kVec;
     extern __shared__ __attribute__((aligned(16))) float ss[];  // [C][2] = {scale, shift}
     __shared__ float s_mean[64], s_rstd[64];
     const int b = blockIdx.y, cpg = C / G;
+    const int CV = C / V;
+    const T* Xb = X + ((int64_t)b * HW) * C;
+    T* Yb = Y + ((int64_t)b * HW) * C;
+    const int vtot = (int)HW * CV;  // (< 2^28: host-checked)
+    const int vbeg = (int)blockIdx.x * span + (int)threadIdx.x;
+    const int vend = (int)blockIdx.x * span + span < vtot ? (int)blockIdx.x * span + span : vtot;
+    uint4 xv[U];
+    gn_rows_request<T, 0, U / 2, U>(Xb, vbeg, vend, xv);
     const int rb = (int)(HW / 64), bpg = cpg / bucket, nba = Ca / bucket, nbb = (C - Ca) / bucket;
     const int items = rb * bpg;
     for (int g0 = 0; g0 < G; g0 += kThreads / 8) {
@@ -266,28 +360,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restri
         ss[2 * c + 1] = beta[c] - s_mean[g] * sc;
     }
     __syncthreads();
-    const int CV = C / V;
-    const int64_t per = (HW + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < HW ? r0 + per : HW;
-    const T* Xb = X + ((int64_t)b * HW) * C;
-    T* Yb = Y + ((int64_t)b * HW) * C;
-    for (int64_t i = r0 * CV + threadIdx.x; i < r1 * CV; i += kThreads) {
-        const int chunk = (int)(i % CV);
-        float v[V];
-        load_vec(Xb + i * V, v);
-        const float* q = ss + (size_t)chunk * V * 2;
-#pragma unroll
-        for (int j = 0; j < V; j += 2) {
-            const float4 t = *reinterpret_cast<const float4*>(q + 2 * j);
-            v[j] = v[j] * t.x + t.y;
-            v[j + 1] = v[j + 1] * t.z + t.w;
-        }
-        if (silu) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) v[j] = silu_f(v[j]);
-        }
-        store_vec_maybe_split<SPLIT_OUT>(Yb, i * V, v);
-    }
+    gn_rows_apply<SPLIT_OUT, T, U>(Xb, Yb, ss, CV, vbeg, vend, silu, xv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,17 +759,34 @@ __global__ __launch_bounds__(kThreads) void layernorm_packed_kernel(const T* __r
                                                                     float eps) {
     GMD_WG_TRACE_SCOPE(WGK_LN_PACKED);
     constexpr int V = Elem<T>::kVec, RPW = 64 / LPR;
+    constexpr int CC = V * LPR * CPL;  // the row length this instance serves (host-checked == C)
+    // Round 5: gamma / beta of the workgroup's rows come from LDS (staged once, under the flight of the row loads).  Read from
+    // global memory per 16-byte chunk they were 20 of the 30 vector-memory instructions of a thread -- twice the L1 traffic of the
+    // rows themselves -- and were requested only after the second reduction.
+    __shared__ __attribute__((aligned(16))) float s_gb[2 * CC];
     const int lane = threadIdx.x & 63, sub = lane % LPR;
     const int64_t row = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
     const bool live = row < rows;  // whole lane groups are live or dead: the DPP sums never mix rows
+    uint4 raw[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int64_t rr = live ? row : rows - 1;  // (clamped: a dead lane group re-reads the last row, never stored)
+        raw[k] = *reinterpret_cast<const uint4*>(X + rr * C + (int64_t)(sub + LPR * k) * V);
+    }
+    for (int c4 = threadIdx.x; c4 < CC / 4; c4 += kThreads) {
+        *reinterpret_cast<float4*>(s_gb + 4 * c4) = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+        *reinterpret_cast<float4*>(s_gb + CC + 4 * c4) = *reinterpret_cast<const float4*>(beta + 4 * c4);
+    }
     float v[CPL][V];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
-        if (live) {
-            load_vec(X + row * C + (int64_t)(sub + LPR * k) * V, v[k]);
+        const unsigned w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] = __uint_as_float(w[e]);
         } else {
 #pragma unroll
-            for (int j = 0; j < V; ++j) v[k][j] = 0.0f;
+            for (int e = 0; e < 4; ++e) Half<T>::unpack2(w[e], v[k][2 * e], v[k][2 * e + 1]);
         }
     }
     float s = 0.0f;
@@ -711,16 +801,17 @@ __global__ __launch_bounds__(kThreads) void layernorm_packed_kernel(const T* __r
 #pragma unroll
         for (int j = 0; j < V; ++j) { const float d = v[k][j] - mean; s2 += d * d; }
     const float rstd = rsqrtf(lane_group_sum<LPR>(s2) / (float)C + eps);
+    __syncthreads();  // gamma / beta are staged
     if (!live) return;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int c0 = (sub + LPR * k) * V;
         float ga[V], be[V], o[V];
-        load_vec(gamma + c0, *reinterpret_cast<float(*)[4]>(&ga[0]));
-        load_vec(beta + c0, *reinterpret_cast<float(*)[4]>(&be[0]));
-        if (V == 8) {
-            load_vec(gamma + c0 + 4, *reinterpret_cast<float(*)[4]>(&ga[V == 8 ? 4 : 0]));
-            load_vec(beta + c0 + 4, *reinterpret_cast<float(*)[4]>(&be[V == 8 ? 4 : 0]));
+#pragma unroll
+        for (int e = 0; e < V; e += 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(s_gb + c0 + e), b4 = *reinterpret_cast<const float4*>(s_gb + CC + c0 + e);
+            ga[e] = g4.x; ga[e + 1] = g4.y; ga[e + 2] = g4.z; ga[e + 3] = g4.w;
+            be[e] = b4.x; be[e + 1] = b4.y; be[e + 2] = b4.z; be[e + 3] = b4.w;
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = (v[k][j] - mean) * rstd * ga[j] + be[j];
@@ -848,23 +939,27 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
     const int CV = C / V, CVB = CV < kThreads ? CV : kThreads, PY = kThreads / CVB;
     const size_t smem = (size_t)PY * C * 2 * sizeof(float);
     GMD_REQUIRE(smem <= 64 * 1024 && (size_t)C * 8 <= 64 * 1024, "gmd_groupnorm_split: C=%d too large", C);
+    GMD_REQUIRE(HW * (int64_t)(C / V) < (1ll << 28), "gmd_groupnorm_split: one sample of %lld x %d exceeds the 32-bit byte offset of the apply pass", (long long)HW, C);
     hipStream_t s = (hipStream_t)stream;
-    // apply slices: about 128 rows each, at least enough workgroups to cover the chip
-    int64_t nb = (HW + 127) / 128;
-    while (nb * B < 512 && nb < HW) nb *= 2;
-    if (nb > HW) nb = HW;
+    // apply slices: 256 * U vectors per workgroup (U <= 10 per thread, in flight in two halves), at least ~512 workgroups where the tensor allows
+    const int64_t nvec = HW * (C / V);
+    const int span_u = gn_apply_span_u(B, nvec), span = kThreads * span_u;
+    const int64_t nb = (nvec + span - 1) / span;
     bool partial_ok = true;
     gmd_for_dtype(dtype, [&](auto tag) {
         using T = decltype(tag);
         gn_partial_kernel<T><<<dim3(nsplit, B), kThreads, smem, s>>>((const T*)X, HW, C, G, nsplit, workspace);
         if (hipGetLastError() != hipSuccess) { partial_ok = false; return; }
-        if constexpr (sizeof(T) == 4) {
-            if (split_out) {
-                gn_apply_ws_kernel<T, true><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, nsplit, eps, workspace, gamma, beta, silu);
-                return;
+        gn_for_u(span_u, [&](auto uc) {
+            constexpr int U = decltype(uc)::value;
+            if constexpr (sizeof(T) == 4) {
+                if (split_out) {
+                    gn_apply_ws_kernel<T, true, U><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, nsplit, eps, workspace, gamma, beta, silu, span);
+                    return;
+                }
             }
-        }
-        gn_apply_ws_kernel<T><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, nsplit, eps, workspace, gamma, beta, silu);
+            gn_apply_ws_kernel<T, false, U><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, nsplit, eps, workspace, gamma, beta, silu, span);
+        });
     });
     if (!partial_ok) {
         gmd_set_error("gmd_groupnorm_split(partial): launch failed");
@@ -886,25 +981,30 @@ int gmd_groupnorm_colstats(const void* X, void* Y, int dtype, int B, int64_t HW,
     const int V = gmd_is_half(dtype) ? 8 : 4;
     GMD_REQUIRE(C % V == 0 && (!split_out || C % 32 == 0) && (size_t)C * 8 <= 64 * 1024, "gmd_groupnorm_colstats: C=%d must be a multiple of %d and at most 8192", C, split_out ? 32 : V);
     GMD_REQUIRE(HW % 64 == 0, "gmd_groupnorm_colstats: the statistics are per 64-row block, HW=%lld is not a multiple of 64", (long long)HW);
+    GMD_REQUIRE(HW * (int64_t)(C / V) < (1ll << 28), "gmd_groupnorm_colstats: one sample of %lld x %d exceeds the 32-bit byte offset of the apply pass", (long long)HW, C);
     GMD_REQUIRE(bucket > 0 && (C / G) % bucket == 0 && Ca > 0 && Ca <= C && Ca % bucket == 0 && (C - Ca) % bucket == 0,
                 "gmd_groupnorm_colstats: bucket=%d must divide the group size %d and both channel ranges (%d, %d)", bucket, C / G, Ca, C - Ca);
     GMD_REQUIRE(Ca == C || stats_b, "gmd_groupnorm_colstats: statistics of the second channel range are missing");
     GMD_REQUIRE((reinterpret_cast<uintptr_t>(stats_a) & 7) == 0 && (reinterpret_cast<uintptr_t>(stats_b) & 7) == 0, "gmd_groupnorm_colstats: statistics must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    int64_t nb = (HW + 127) / 128;
-    while (nb * B < 512 && nb < HW) nb *= 2;
-    if (nb > HW) nb = HW;
+    // apply slices: 256 * U vectors per workgroup (U <= 10 per thread, in flight in two halves), at least ~512 workgroups where the tensor allows
+    const int64_t nvec = HW * (C / V);
+    const int span_u = gn_apply_span_u(B, nvec), span = kThreads * span_u;
+    const int64_t nb = (nvec + span - 1) / span;
     gmd_for_dtype(dtype, [&](auto tag) {
         using T = decltype(tag);
-        if constexpr (sizeof(T) == 4) {
-            if (split_out) {
-                gn_apply_cs_kernel<T, true><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, eps, stats_a, Ca,
-                                                                                                  stats_b, bucket, gamma, beta, silu);
-                return;
+        gn_for_u(span_u, [&](auto uc) {
+            constexpr int U = decltype(uc)::value;
+            if constexpr (sizeof(T) == 4) {
+                if (split_out) {
+                    gn_apply_cs_kernel<T, true, U><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, eps, stats_a, Ca,
+                                                                                                         stats_b, bucket, gamma, beta, silu, span);
+                    return;
+                }
             }
-        }
-        gn_apply_cs_kernel<T><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, eps, stats_a, Ca,
-                                                                                    stats_b, bucket, gamma, beta, silu);
+            gn_apply_cs_kernel<T, false, U><<<dim3((unsigned)nb, B), kThreads, (size_t)C * 8, s>>>((const T*)X, (T*)Y, HW, C, G, eps, stats_a, Ca,
+                                                                                               stats_b, bucket, gamma, beta, silu, span);
+        });
     });
     GMD_CHECK_LAUNCH("gmd_groupnorm_colstats");
     return GMD_OK;
