@@ -303,17 +303,22 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, const f3
     if (lane < NCOL / 4)
         *reinterpret_cast<float4*>(strip + lane * ROWF + NCOL) = p.bias ? *reinterpret_cast<const float4*>(p.bias + nw + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool rb_pre = PLAIN && p.rowbias != nullptr && p.residual == nullptr;  // row bias alone (conv1 of a ResnetBlock2D): prefetched per half
+    // (residual rows of half hh -> resv[hh & 1]: half 0 here, half h + 1 below, behind the staging of half h -- its accumulators are
+    //  dead by then, so the 20 registers are free -- and in front of half h's items, which hide its L2 / HBM latency; requested at the
+    //  top of its own half, as before, the second half's latency was exposed once more per wave tile)
+    auto request_residual = [&](int hh) {
+#pragma unroll
+        for (int t = 0; t < ITER; ++t) {
+            const int idx = lane + 64 * t;
+            const int r = idx / CH, c = idx - r * CH;
+            if (32 * CH % 64 != 0 && r >= 32) continue;
+            resv[hh & 1][t] = *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)(mw + hh * 32 + r) * p.ldr + nw + c * 8);
+        }
+    };
+    const bool res_pre = PLAIN && p.residual != nullptr;  // (the activation instances -- time-embedding MLP, text encoder: tiny launches -- load in place)
+    if (res_pre) request_residual(0);
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
-        if (PLAIN && p.residual) {  // (the activation instances -- time-embedding MLP, text encoder: tiny launches -- load in place)
-#pragma unroll
-            for (int t = 0; t < ITER; ++t) {
-                const int idx = lane + 64 * t;
-                const int r = idx / CH, c = idx - r * CH;
-                if (32 * CH % 64 != 0 && r >= 32) continue;
-                resv[0][t] = *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)(mw + h * 32 + r) * p.ldr + nw + c * 8);
-            }
-        }
         if (rb_pre) {
 #pragma unroll
             for (int t = 0; t < ITER; ++t) {
@@ -335,6 +340,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, const f3
                     make_float4(acc[2 * h + i2][j][0], acc[2 * h + i2][j][1], acc[2 * h + i2][j][2], acc[2 * h + i2][j][3]);
         __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS: only the compiler must not reorder across this point
         EPI_STAMP()
+        if (res_pre && h + 1 < TM / 2) request_residual(h + 1);
 #pragma unroll
         for (int t = 0; t < ITER; ++t) {
             const int idx = lane + 64 * t;
@@ -346,7 +352,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, const f3
             float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (p.residual) {
-                const uint4 w = PLAIN ? resv[0][t] : *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
+                const uint4 w = PLAIN ? resv[h & 1][t] : *reinterpret_cast<const uint4*>((const HT*)p.residual + (int64_t)z * p.sR + (int64_t)m * p.ldr + n);
                 const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) Half<HT>::unpack2(ww[e], add[2 * e], add[2 * e + 1]);
