@@ -450,6 +450,17 @@ __global__ __launch_bounds__(256, D <= 40 ? 4 : (D <= 64 ? 3 : 1)) void attn_fwd
 // ------------------------------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// (experiment hooks, compiled to nothing in the product: static priority of a wave's MFMA / softmax segments, tools/dbg)
+#if defined(GMD_ATTN40_PRIO) && GMD_ATTN40_PRIO == 1
+#define ATTN40_PRIO_MFMA(x) __builtin_amdgcn_s_setprio(x);
+#define ATTN40_PRIO_VALU(x)
+#elif defined(GMD_ATTN40_PRIO) && GMD_ATTN40_PRIO == 2
+#define ATTN40_PRIO_MFMA(x)
+#define ATTN40_PRIO_VALU(x) __builtin_amdgcn_s_setprio(x);
+#else
+#define ATTN40_PRIO_MFMA(x)
+#define ATTN40_PRIO_VALU(x)
+#endif
 template <typename HT>
 __global__ __launch_bounds__(256, 4) void attn40_kernel(const AttnParams p) {
     GMD_WG_TRACE_SCOPE(WGK_ATTN40);
@@ -637,8 +648,11 @@ __global__ __launch_bounds__(256, 4) void attn40_kernel(const AttnParams p) {
         if (kt + 2 < ntiles) issue(kt + 2, (STAGE + 2) % NST);  // that stage held tile kt-1
 
         f32x16 st[2];
+        ATTN40_PRIO_MFMA(1)
 #pragma unroll
         for (int t = 0; t < 2; ++t) st[t] = first_product(Sb, t);
+        ATTN40_PRIO_MFMA(0)
+        ATTN40_PRIO_VALU(1)
         // register i of key block t, lane half hh  <->  key k0 + 32 t + 16 (i >> 3) + 8 hh + (i & 7)
         if (k0 + KV > p.Nk) {
 #pragma unroll
@@ -691,11 +705,14 @@ __global__ __launch_bounds__(256, 4) void attn40_kernel(const AttnParams p) {
                 w.w = Half<HT>::pack2(st[t][8 * s + 6], st[t][8 * s + 7]);
                 pf[2 * t + s] = w;
             }
+        ATTN40_PRIO_VALU(0)
+        ATTN40_PRIO_MFMA(1)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             ot[0] = Half<HT>::mfma32(*reinterpret_cast<const uint4*>(Sb + v0[ks]), pf[ks], ot[0]);
             ot[1] = Half<HT>::mfma32(*reinterpret_cast<const uint4*>(Sb + v1[ks]), pf[ks], ot[1]);
         }
+        ATTN40_PRIO_MFMA(0)
         if constexpr (LAG) {
             if (!__all(alpha == 1.0f)) {
 #pragma unroll

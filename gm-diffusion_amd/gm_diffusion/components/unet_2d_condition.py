@@ -450,10 +450,13 @@ class UNet2DConditionModel(_HipModule):
                 for nm in ("norm1", "norm2", "norm3"):
                     blk[nm] = self._norm(f"{b}.{nm}")
                 q1, k1 = self._raw[f"{b}.attn1.to_q.weight"], self._raw[f"{b}.attn1.to_k.weight"]
-                blk["qk1"] = self._wt(torch.cat([q1, k1], 0))  # fused [2C, C] projection
                 blk["v1"] = self._wa(self._raw[f"{b}.attn1.to_v.weight"])
                 # q | k | v stacked: ONE launch writes Q|K row-major and V transposed (hip_ops.gemm_qkv_vt; 16-bit and float32 split modes)
                 blk["qkv1"] = self._wt(torch.cat([q1, k1, self._raw[f"{b}.attn1.to_v.weight"]], 0))
+                # fused [2C, C] projection of the fallback path.  16-bit modes: the first 2C rows of the stacked matrix (a contiguous
+                # view, no third copy of q | k: ~62 MB per SD-1.5 UNet); the float32 split mode keeps its own copy, because a pre-split
+                # weight carries ONE power-of-two scale for the whole matrix and q | k alone would get another
+                blk["qk1"] = blk["qkv1"][: q1.shape[0] + k1.shape[0]] if ops.is_half(self._dtype) else self._wt(torch.cat([q1, k1], 0))
                 blk["o1"] = self._lin(f"{b}.attn1.to_out.0")
                 blk["q2"] = self._lin(f"{b}.attn2.to_q", False)[0]
                 blk["k2"] = self._lin(f"{b}.attn2.to_k", False)[0]
