@@ -2460,6 +2460,13 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
                         found = true;
                     }
             }
+            // still nothing (the GM UNet's 16x16 projections at batch 4, M = 1024 N = K = 1280: 128 tiles of 64 x 160, K too short to
+            // slice): 64 x 128 loader / consumer tiles, a quarter more workgroups than 64 x 160 (tools/dbg/sweep_rows.py: 13.7 us on the
+            // legacy 64 x 64 kernel -> 11.3 us; the vendor library 11.5)
+            if (!found && !want_cs && N % 128 == 0 && nk >= 8) {  // (validated for K >= 512 only)
+                const int64_t t = (int64_t)((M + 63) / 64) * (N / 128);
+                if (t >= 144 && t <= 256) pl = Plan{64, 128, 244, 1};
+            }
         }
     }
     return pl;

@@ -2,7 +2,7 @@
 # the library yardstick, the shape census of one loop iteration under the co-running plan family, the two-stream timeline.
 set -x
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5z; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${EVID_DIR:-r5z}; mkdir -p $O
 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err
 rm -rf /tmp/prof; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_line_profiled.json 2> $O/prof.err
 T=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); S=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
