@@ -478,10 +478,16 @@ USE_FUSED_FF = os.environ.get("GMD_FUSED_FF", "1") != "0"
 # One 128-row workgroup per CU: below ~7/8 of the chip's 256 CUs the two tiled GEMM launches (two workgroups per CU, 512+ tiles)
 # are faster -- tools/bench_ff.py: M = 32768 90 vs 124 us, M = 16384 (half the chip) 82 vs 67 us.
 FUSED_FF_MIN_ROWS = int(os.environ.get("GMD_FUSED_FF_MIN_ROWS", str(224 * 128)))
+# ... inside a co-running forward (plan family 1) from half the chip up: beside the other stream's kernels CU-time, not the launch's
+# own time, is what counts, and 128 fused workgroups cost less of it than the 1280 + 256 of the two launches (round 5, interleaved
+# A/B of whole bench.py runs: 752.7 -> 751.3 ms per batch, 3 of 3 rounds; fusion off altogether: 757.4)
+FUSED_FF_MIN_ROWS_CO_RUN = int(os.environ.get("GMD_FUSED_FF_MIN_ROWS_CO_RUN", str(128 * 128)))
 
 
 def ff_fused_ok(x, C, min_rows=None):
-    return (USE_FUSED_FF and is_half(x.dtype) and x.dim() == 2 and x.shape[0] >= (FUSED_FF_MIN_ROWS if min_rows is None else min_rows) and
+    if min_rows is None:
+        min_rows = FUSED_FF_MIN_ROWS_CO_RUN if lib().gmd_gemm_plan_family(-1) == 1 else FUSED_FF_MIN_ROWS
+    return (USE_FUSED_FF and is_half(x.dtype) and x.dim() == 2 and x.shape[0] >= min_rows and
             bool(lib().gmd_ff_geglu_fused_supported(dtype_code(x.dtype), x.shape[0], C)))
 
 

@@ -998,6 +998,8 @@ def test_ff_geglu_fused_matches_two_gemms_and_float64(dtype, M):
     assert rel_err(got.float(), two.float()) < t  # both round H to the 16-bit type once; only the summation order differs
     assert not o.ff_fused_ok(xd[:100], C, min_rows=0) and not o.ff_fused_ok(torch.zeros(128, 640, dtype=dtype, device=DEV), 640, min_rows=0)
     assert o.ff_fused_ok(xd, C) == (M >= o.FUSED_FF_MIN_ROWS)  # the product path takes it only where it fills the chip
+    with o.plan_family(1):  # ... and, inside a co-running forward, from half the chip up (CU-time beside the other stream's kernels)
+        assert o.ff_fused_ok(xd, C) == (M >= o.FUSED_FF_MIN_ROWS_CO_RUN)
 
 
 # B, H, Cin, Cout, split-K expected, accesses per thread class
