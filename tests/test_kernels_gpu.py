@@ -248,7 +248,30 @@ def test_groupnorm(dtype, B, HW, C, G):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("rows,C", [(5, 320), (130, 640), (64, 1280), (3, 64), (9, 2048)])
+@pytest.mark.parametrize("B,HW,C,expect_u", [(1, 4163, 320, 2), (4, 4100, 320, 4), (5, 4100, 320, 6), (8, 4100, 320, 10), (3, 8200, 960, 10), (2, 3300, 640, 4)])
+def test_groupnorm_apply_pass_every_vector_count_and_ragged_ends(dtype, B, HW, C, expect_u):
+    """Round 5: the apply pass of the split-statistics GroupNorm is loop-free -- a workgroup owns 256 * U consecutive 16-byte vectors
+    of a sample (U in {2, 4, 6, 10} by tensor size: four kernel instantiations), requests them in two halves around the statistics
+    fold and stores through a range-checked buffer descriptor.  Every U, with sample sizes that are NOT a multiple of the span (the
+    last workgroup's clamped loads / dropped stores) and a row count that is not a multiple of anything, against float64 torch."""
+    o = ops()
+    V = 8 if dtype in HALF else 4
+    u = (HW * (C // V) * B) // (512 * 256)
+    U = 10 if u >= 10 else 6 if u >= 6 else 4 if u >= 4 else 2  # gn_apply_span_u (csrc/norm.hip)
+    if dtype in HALF:  # the 16-bit cases walk all four instantiations, each with a ragged last workgroup (float32: twice the vectors)
+        assert U == expect_u and (HW * (C // V)) % (256 * U) != 0
+    g = torch.Generator().manual_seed(B * HW + C)
+    x = (torch.randn(B, HW, C, generator=g) * 1.5 - 0.25).to(dtype)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    for silu in (True, False):
+        ref = F.group_norm(x.double().permute(0, 2, 1).reshape(B, C, HW, 1), 32, gamma.double(), beta.double(), 1e-5)
+        ref = (F.silu(ref) if silu else ref).reshape(B, C, HW).permute(0, 2, 1)
+        got = o.groupnorm(x.to(DEV), B, 32, gamma.to(DEV), beta.to(DEV), 1e-5, silu=silu)
+        assert got.shape == x.shape and rel_err(got.double().cpu(), ref) < (3e-6 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,C", [(5, 320), (130, 640), (64, 1280), (3, 64), (9, 2048), (4099, 320), (1031, 640), (32768, 320)])
 def test_layernorm(dtype, rows, C):
     o = ops()
     g = torch.Generator().manual_seed(rows)
