@@ -2616,11 +2616,17 @@ const char* plan_unsupported(const Plan& pl, const GemmParams& p, int batch, int
 int pick_tile_group(const Plan& pl, int M, int N, int K) {
     if (pl.pf != 283 && pl.pf != 244) return 1;
     const int tiles_m = (M + pl.bm - 1) / pl.bm;
-    if (N > M) return tiles_m;
     const int64_t w_bytes = (int64_t)N * K * 2;
-    if (w_bytes <= (3ll << 20)) return 1;
-    int g = (tiles_m + 7) / 8;  // the XCD's share of M-panels
-    if (g > 8) g = 8;
+    int g;
+    if (N > M) g = tiles_m;
+    else if (w_bytes <= (3ll << 20)) return 1;
+    else g = (tiles_m + 7) / 8;  // the XCD's share of M-panels
+    // Round 5: at most FOUR M-panels per group.  An XCD walks its run of tiles one W panel at a time over the group's A panels: the
+    // A panels must survive in its 4 MiB L2 beside the W panels in flight and the output lines passing through, the W panels are
+    // streamed once.  rocprofv3 FETCH_SIZE against the group (profiles/r05_pmc_tile_group.txt, MB read, algorithmic in brackets):
+    // M=4096 N=5120 K=640 [11.8]: 16 (the N > M rule) 126, 8: 50, 4: 37.5, 2: 59;  M=2048 N=10240 K=1280 [31.5]: 8 (N > M) 145, 4: 110,
+    // 2: 130;  M=8192 N=5120 K=640 [17]: 4 (the share rule) 66, 8: 84, 2: 121;  M=1024 N=10240 K=1280: 4 = all its panels, 63.
+    if (g > 4) g = 4;
     return g < 1 ? 1 : g;
 }
 

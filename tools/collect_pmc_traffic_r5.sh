@@ -31,7 +31,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc "gemm 2048 1280 5120 res" $c python3 $R/tools/one_gemm.py 2048 1280 5120 res
   pmc "gemm 8192 640 2560 res" $c python3 $R/tools/one_gemm.py 8192 640 2560 res
   pmc "gemm 1024 10240 1280 geglu" $c python3 $R/tools/one_gemm.py 1024 10240 1280 geglu
-  pmc "gemm 16384 2560 320 geglu" $c python3 $R/tools/one_gemm.py 16384 2560 320 geglu
+  pmc "ff_geglu_fused 16384" $c python3 $R/tools/one_ff.py 16384
   pmc "gemm 4096 5120 640 geglu" $c python3 $R/tools/one_gemm.py 4096 5120 640 geglu
   pmc "conv 8 64 64 640 320" $c python3 $R/tools/one_conv.py 8 64 64 640 320
   pmc "conv 8 64 64 320 320" $c python3 $R/tools/one_conv.py 8 64 64 320 320
