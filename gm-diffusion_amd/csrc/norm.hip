@@ -199,7 +199,7 @@ __device__ __forceinline__ void gn_rows_apply(const T* Xb, T* Yb, const float* s
     int c = vbeg % CV;
     const int step = kThreads % CV;
     gn_rows_request<T, U / 2, U, U>(Xb, vbeg, vend, raw);
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(Yb, 0, vend * 16, 0x00020000);  // (vend < 2^28: host-checked)
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(Yb, 0, vend * 16, 0x00020000);  // (vend < 2^27, so byte offsets stay positive ints: host-checked)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = vbeg + u * kThreads;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_ws_kernel(const T* __restri
     const int CV = C / V;
     const T* Xb = X + ((int64_t)b * HW) * C;
     T* Yb = Y + ((int64_t)b * HW) * C;
-    const int vtot = (int)HW * CV;  // (< 2^28: host-checked)
+    const int vtot = (int)HW * CV;  // (< 2^27: host-checked)
     const int vbeg = (int)blockIdx.x * span + (int)threadIdx.x;
     const int vend = (int)blockIdx.x * span + span < vtot ? (int)blockIdx.x * span + span : vtot;
     uint4 xv[U];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void gn_apply_cs_kernel(const T* __restri
     const int CV = C / V;
     const T* Xb = X + ((int64_t)b * HW) * C;
     T* Yb = Y + ((int64_t)b * HW) * C;
-    const int vtot = (int)HW * CV;  // (< 2^28: host-checked)
+    const int vtot = (int)HW * CV;  // (< 2^27: host-checked)
     const int vbeg = (int)blockIdx.x * span + (int)threadIdx.x;
     const int vend = (int)blockIdx.x * span + span < vtot ? (int)blockIdx.x * span + span : vtot;
     uint4 xv[U];
@@ -939,7 +939,7 @@ int gmd_groupnorm_split(const void* X, void* Y, int dtype, int B, int64_t HW, in
     const int CV = C / V, CVB = CV < kThreads ? CV : kThreads, PY = kThreads / CVB;
     const size_t smem = (size_t)PY * C * 2 * sizeof(float);
     GMD_REQUIRE(smem <= 64 * 1024 && (size_t)C * 8 <= 64 * 1024, "gmd_groupnorm_split: C=%d too large", C);
-    GMD_REQUIRE(HW * (int64_t)(C / V) < (1ll << 28), "gmd_groupnorm_split: one sample of %lld x %d exceeds the 32-bit byte offset of the apply pass", (long long)HW, C);
+    GMD_REQUIRE(HW * (int64_t)(C / V) < (1ll << 27), "gmd_groupnorm_split: one sample of %lld x %d exceeds the 32-bit byte offset of the apply pass", (long long)HW, C);
     hipStream_t s = (hipStream_t)stream;
     // apply slices: 256 * U vectors per workgroup (U <= 10 per thread, in flight in two halves), at least ~512 workgroups where the tensor allows
     const int64_t nvec = HW * (C / V);
@@ -981,7 +981,7 @@ int gmd_groupnorm_colstats(const void* X, void* Y, int dtype, int B, int64_t HW,
     const int V = gmd_is_half(dtype) ? 8 : 4;
     GMD_REQUIRE(C % V == 0 && (!split_out || C % 32 == 0) && (size_t)C * 8 <= 64 * 1024, "gmd_groupnorm_colstats: C=%d must be a multiple of %d and at most 8192", C, split_out ? 32 : V);
     GMD_REQUIRE(HW % 64 == 0, "gmd_groupnorm_colstats: the statistics are per 64-row block, HW=%lld is not a multiple of 64", (long long)HW);
-    GMD_REQUIRE(HW * (int64_t)(C / V) < (1ll << 28), "gmd_groupnorm_colstats: one sample of %lld x %d exceeds the 32-bit byte offset of the apply pass", (long long)HW, C);
+    GMD_REQUIRE(HW * (int64_t)(C / V) < (1ll << 27), "gmd_groupnorm_colstats: one sample of %lld x %d exceeds the 32-bit byte offset of the apply pass", (long long)HW, C);
     GMD_REQUIRE(bucket > 0 && (C / G) % bucket == 0 && Ca > 0 && Ca <= C && Ca % bucket == 0 && (C - Ca) % bucket == 0,
                 "gmd_groupnorm_colstats: bucket=%d must divide the group size %d and both channel ranges (%d, %d)", bucket, C / G, Ca, C - Ca);
     GMD_REQUIRE(Ca == C || stats_b, "gmd_groupnorm_colstats: statistics of the second channel range are missing");
