@@ -160,9 +160,8 @@ __device__ __forceinline__ void store_vec_maybe_split(T* Y, int64_t e, const flo
 // sample (U in {2, 4, 6, 10}, chosen by the host: gn_apply_span_u), thread t the vectors first + t + 256 u; channel chunk = index mod CV, scale /
 // shift per channel in LDS.  Round 5: a thread's loads are requested in two halves around the statistics fold (X does not
 // depend on it, see gn_rows_apply) and there is no loop -- the old form kept ONE 16-byte load per thread outstanding behind a 64-bit modulo (2048
-// waves x 1 KB = 2 MB in flight on the whole chip: 1.9-3.4 TB/s alone, less beside a second stream).  A load is skipped only where
-// the WHOLE wave is past the end (scalar branch); inside a partly valid wave the index is clamped -- a load inside a per-lane
-// `if (i < vend)` is waited for right there, one at a time.
+// waves x 1 KB = 2 MB in flight on the whole chip: 1.9-3.4 TB/s alone, less beside a second stream).  Loads are unconditional with a
+// clamped index and stores go through a range-checked buffer descriptor, so the pass is ONE basic block (see gn_rows_request).
 typedef unsigned gn_u32x4 __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ void gn_unpack16(const uint4& r, float (&v)[Elem<T>::kVec]) {
