@@ -219,6 +219,34 @@ def test_pp_geglu_epilogue_vs_float64(dtype, tol, force_plan):
     assert y.shape == (M, 4 * C) and _rel(y.cpu(), ref) < tol
 
 
+@pytest.mark.parametrize("M,C", [(1536, 640), (4096, 640), (1280, 1280), (8192, 640)])
+def test_tile_groups_of_four_m_panels_geglu_vs_float64(M, C):
+    """Round 5: the XCD-aware tile order walks W-heavy launches in groups of at most FOUR M-panels (pick_tile_group, csrc/gemm.hip:
+    the group's A panels have to stay in the XCD's L2).  The GEGLU projections of the co-running plan family on row counts that give
+    one whole group, several groups, and a short last group (6 and 5 M-panels), against float64: every tile exactly once."""
+    from gm_diffusion import hip_ops as ops
+
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).bfloat16().to(DEV)
+    w1 = (torch.randn(8 * C, C, generator=g) * 0.04).bfloat16()
+    b1 = torch.randn(8 * C, generator=g) * 0.5
+    half = 4 * C
+    wi = torch.stack([w1[:half].reshape(half // 16, 16, -1), w1[half:].reshape(half // 16, 16, -1)], 1).reshape(2 * half, -1).contiguous().to(DEV)
+    bi = torch.stack([b1[:half].reshape(half // 16, 16), b1[half:].reshape(half // 16, 16)], 1).reshape(2 * half).contiguous().to(DEV)
+    with ops.plan_family(1):
+        assert ops.gemm_plan_info(torch.bfloat16, M, 8 * C, C, 1, True)[:3] == (256, 128, 283)
+        y = ops.gemm_nt(x, wi, bias=bi, act=ops.ACT_GEGLU)
+    h = x.double().cpu() @ w1.double().T + b1.double()
+    ref = h[:, :half] * F.gelu(h[:, half:])
+    assert y.shape == (M, half) and _rel(y.cpu(), ref) < 6e-3
+    # ... and a plain W-heavy projection with residual through the same order (N > M: the rule that used to take all M-panels)
+    w2 = (torch.randn(4 * C, C, generator=g) * 0.04).bfloat16().to(DEV)
+    r = torch.randn(M, 4 * C, generator=g).bfloat16().to(DEV)
+    with ops.plan_family(1):
+        y2 = ops.gemm_nt(x, w2, residual=r)
+    assert _rel(y2.cpu(), x.double().cpu() @ w2.double().cpu().T + r.double().cpu()) < 4e-3
+
+
 def test_pp_column_statistics_feed_groupnorm(force_plan):
     """Producer statistics out of the ping-pong kernel's row epilogue (same strips and bucket layout as the ring kernels): sums of
     the STORED values per 64 rows x 10 channels, and GroupNorm from them == GroupNorm of the stored tensor."""
