@@ -2334,12 +2334,16 @@ struct Force {
 Force g_force;  // read once when the library is loaded
 // GMD_PP=0 keeps the round-3 plans (A/B measurements of whole runs; read once when the library is loaded)
 const bool g_pp_enabled = [] { const char* e = getenv("GMD_PP"); return !(e && e[0] == '0'); }();
-// How stride-1 convolutions on 256-row ping-pong tiles fetch their activations: 2 (default) = input patch resident in LDS, continuous
-// consumers (conv_patch_cont_kernel); 1 = patch resident, ping-pong consumers (conv_patch_kernel); 0 = per-tap implicit GEMM
-// (gemm_pp_kernel<CONV>).  GMD_CONV_PATCH seeds it when the library is loaded; gmd_conv_patch_override() changes it in-process for A/B
-// runs and tests (GMD_TUNING=1 only).  Whole-run A/B (profiles/r04_ab_bench_plan_families.txt): 838.7 / 840.6 / 837.5 ms for 0 / 1 / 2
-// -- level by time, but the patch forms pull half the bytes from L2 (25.6 instead of 52 KB per K step).
-int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
+// How stride-1 convolutions on 256-row ping-pong tiles fetch their activations: 0 (default since the end of round 5) = per-tap implicit
+// GEMM (gemm_pp_kernel<CONV>); 2 = input patch resident in LDS, continuous consumers (conv_patch_cont_kernel); 1 = patch resident,
+// ping-pong consumers (conv_patch_kernel).  GMD_CONV_PATCH seeds it when the library is loaded; gmd_conv_patch_override() changes it
+// in-process for A/B runs and tests (GMD_TUNING=1 only).  Whole-run A/Bs: round 4 (launch-by-launch plans) 838.7 / 840.6 / 837.5 ms for
+// 0 / 1 / 2 -- level, and the patch forms pull half the bytes from L2 (25.6 instead of 52 KB per K step), so 2 became the default; at
+// the end of round 5 (co-running plan family, in-kernel reduction, the shorter epilogue) the per-tap kernel is 1.0 % FASTER on the wall
+// of the two-stream pipeline (764.1 -> 756.4 ms, 4 of 4 interleaved rounds; 765.1 -> 756.8, 2 of 2), level with the streams serialised
+// (922.1 / 921.0) and at batch 8 (1266.6 / 1265.2), and level or ahead launch by launch (8x64x64 320->320 61.0 -> 58.4 us, 640->320
+// 113.7 -> 111.4): profiles/r05_ab_conv_patch_mode.txt.  The patch kernels stay in the library (tests, A/B).
+int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0; }();
 // Plan family (round 5, see make_plan): 0 = the plan that is fastest launch by launch when the launch has the chip to itself (direct
 // calls, single-stream pipelines, the VAE); 1 = the co-running family -- 256-row tiles everywhere, filled up with K slices -- for
 // launches that share the chip with a second stream's kernels (the dual-UNet pipeline's two forwards).  The calling thread selects

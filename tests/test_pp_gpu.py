@@ -25,7 +25,7 @@ def force_plan():
 
     yield force
     lib().gmd_gemm_plan_override(0, 0, 0, 0)
-    lib().gmd_conv_patch_override(2)
+    lib().gmd_conv_patch_override(0)  # the default (per-tap implicit GEMM since the end of round 5)
     if prev is None:
         os.environ.pop("GMD_TUNING", None)
     else:
@@ -297,7 +297,7 @@ def test_conv_patch_kernel_vs_float64(B, H, W, ci, co, ks, mode, force_plan):
     from gm_diffusion._native import lib
 
     force_plan(256, 160 if co % 160 == 0 else 128, 283, ks)
-    assert lib().gmd_conv_patch_override(mode) == 0  # 2: continuous consumers (the default), 1: ping-pong consumers
+    assert lib().gmd_conv_patch_override(mode) == 0  # 2: continuous consumers (the default until the end of round 5), 1: ping-pong consumers
     y, ho, wo = ops.conv3x3(x, w, B, H, W, bias=b, rowbias=tb, residual=r)
     ref = _conv_ref(x, w, B, H, W, bias=b, rowbias=tb, residual=r)
     assert (ho, wo) == (H, W) and _rel(y, ref) < 4e-3
@@ -315,10 +315,11 @@ def test_conv_patch_kernel_f16_and_column_statistics(force_plan):
     x = torch.randn(B, H * H, ci, generator=g).half().to(DEV)
     w = (torch.randn(co, 9 * ci, generator=g) * 0.03).half().to(DEV)
     b = torch.randn(co, generator=g).to(DEV)
+    from gm_diffusion._native import lib
     force_plan(256, 160, 283, 1)
+    assert lib().gmd_conv_patch_override(2) == 0  # (the patch-resident kernel: not the default any more)
     y, _, _ = ops.conv3x3(x, w, B, H, H, bias=b)
     assert _rel(y, _conv_ref(x, w, B, H, H, bias=b)) < 5e-4
-    from gm_diffusion._native import lib
     lib().gmd_gemm_plan_override(0, 0, 0, 0)
     # heuristic path with producer statistics (M = 32768 at 64x64 x 8: ping-pong tiles, unsplit)
     B, H, ci, co = 8, 64, 64, 320
