@@ -2350,6 +2350,14 @@ int g_conv_patch_mode = [] { const char* e = getenv("GMD_CONV_PATCH"); return (e
 // it with gmd_gemm_plan_family(); GMD_PP=b / GMD_PP=1 pin family 1 / 0 for the whole process (A/B runs), read once at load time.
 const int g_family_pin = [] { const char* e = getenv("GMD_PP"); return (e && e[0] == 'b') ? 1 : ((e && e[0] == '1') ? 0 : -1); }();
 thread_local int t_plan_family = 0;
+// K slices of the co-running family: until about g_f1_target workgroups, at least g_f1_min_steps K steps each (GMD_F1_TARGET /
+// GMD_F1_MIN_STEPS: whole-run A/B only).  The target was 256 -- one workgroup per CU -- until the end of round 5; HALF the chip is
+// better: 256 -> 128: 761.5 -> 744.5 ms per batch (-2.2 %, 3 of 3 interleaved rounds), 1320.4 -> 1307.3 at batch 8 (-1.0 %); 160 / 144:
+// 747.7 / 746.3; 112: 766.8 (the 80-tile projections lose their second slice); 96 / 64 / 32: 768.9 / 780.3 / 813.8; 320: +4.4 %
+// (profiles/r05_ab_f1_slice_target.txt).  Fewer slices = fewer prologues, fragment round trips and finisher waits per product: CU-time,
+// which is what two forwards sharing the chip pay for; the other stream fills the CUs a launch leaves free.
+const int g_f1_target = [] { const char* e = getenv("GMD_F1_TARGET"); return e ? atoi(e) : 128; }();
+const int g_f1_min_steps = [] { const char* e = getenv("GMD_F1_MIN_STEPS"); return e ? atoi(e) : 8; }();
 const bool g_f1_bn128 = [] { const char* e = getenv("GMD_F1_BN128"); return !(e && e[0] == '0'); }();  // GMD_F1_BN128=0: A/B
 // In-kernel split-K reduction up to this many K slices (0 = off: slabs + reduction launch everywhere).  GMD_SPLITK_FIXUP=<n>, read once.
 int g_fixup_max = [] { const char* e = getenv("GMD_SPLITK_FIXUP"); return e ? atoi(e) : 4; }();  // gmd_splitk_fixup_max() changes it in-process
@@ -2427,9 +2435,9 @@ Plan make_plan(int M, int N, int K, int batch, int64_t ws_bytes, bool pair_tiles
             } else if (bn && M >= 256) {
                 auto slices = [&](int bnc) {
                     const int64_t t = mt256 * (N / bnc);
-                    int ks = t >= 256 ? 1 : (int)((256 + t / 2) / t);
+                    int ks = t >= g_f1_target ? 1 : (int)((g_f1_target + t / 2) / t);
                     if (ks > 8) ks = 8;
-                    while (ks > 1 && (nk / ks < 8 || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
+                    while (ks > 1 && (nk / ks < g_f1_min_steps || (int64_t)ks * M * N * (int64_t)sizeof(float) > ws_bytes)) --ks;
                     return ks;
                 };
                 int bnc = bn;
